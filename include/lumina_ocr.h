@@ -1,0 +1,102 @@
+/* lumina_ocr.h — C ABI of the MI355X-native det+rec OCR engine (liblumina_ocr.so).
+ *
+ * This is the drop-in boundary underneath the reference's OCR-provider interface.  The reference
+ * has no FFI for this path: its provider is a Python module whose engine slot is one call,
+ *   Azure : /root/reference/backend/services/ocr_service.py:213-246  (_analyze_with_azure)
+ *   Paddle: /root/reference/backend/services/ocr_service_paddleocr_backup.py:285 (pipeline.predict)
+ * and whose result is reshaped by ocr_service.py:248-376 (_extract_layout_boxes).  The entry
+ * points below are what a ctypes binding inside that slot calls (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; it never throws and never
+ *     aborts.  lumina_ocr_last_error() returns a description of the last failure on the handle
+ *     (the reference's error convention is "errors are data": ocr_service.py:464-475).
+ *   - all *_dev pointers are device pointers owned by the caller (e.g. torch-ROCm tensors,
+ *     tensor.data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     Work is enqueued asynchronously on that stream unless stated otherwise.
+ *   - a handle is bound to one device and must not be used from two threads at once (the
+ *     reference serialises pages with a Semaphore(1): ocr_service.py:157, :404).
+ *   - images are uint8 HWC RGB; activations are bf16 NHWC; the probability map is bf16.
+ */
+#ifndef LUMINA_OCR_H
+#define LUMINA_OCR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lumina_ocr lumina_ocr_t;
+
+#define LUMINA_REC_H 32
+#define LUMINA_REC_W 320
+#define LUMINA_REC_T 80
+#define LUMINA_MAX_BOXES 1000 /* DB max_candidates; box buffers are [B][LUMINA_MAX_BOXES][8] */
+
+/* lifecycle — replaces OCRService._ensure_client_initialized (ocr_service.py:166-207) */
+int lumina_ocr_create(int device, lumina_ocr_t** out);
+void lumina_ocr_destroy(lumina_ocr_t* h);
+const char* lumina_ocr_last_error(const lumina_ocr_t* h);
+const char* lumina_ocr_version(void);
+/* options: "det_sub_batch", "rec_sub_batch", "keep_taps", "time_convs" */
+int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value);
+
+/* weights: "LOCW" container (ocr-system_amd/lumina_ocr/arch.py write_blob), host memory.
+ * Replaces PaddleOCRVL(...) model construction (ocr_service_paddleocr_backup.py:204-253). */
+int lumina_ocr_load_det_weights(lumina_ocr_t* h, const void* blob, size_t nbytes);
+int lumina_ocr_load_rec_weights(lumina_ocr_t* h, const void* blob, size_t nbytes);
+int lumina_ocr_num_classes(const lumina_ocr_t* h);
+
+/* image -> tensor: xn = bf16(u8 * scale[c] + shift[c]), zero outside (valid_h, valid_w).
+ * layout_nchw = 1 writes [N,3,Hp,Wp], 0 writes [N,Hp,Wp,3]. */
+int lumina_ocr_normalize(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, int hp, int wp,
+                         const float scale[3], const float shift[3], int layout_nchw, uint16_t* out_dev, void* stream);
+
+/* DBNet (ResNet18_vd + DBFPN + DBHead): pages_dev uint8 [B,H,W,3] -> prob_dev bf16 [B,Hp,Wp],
+ * Hp, Wp multiples of 32, >= H, W (the page is zero-padded in normalised space).
+ * This is the arithmetic of the engine slot (ocr_service.py:231-238). */
+int lumina_ocr_det_forward(lumina_ocr_t* h, const uint8_t* pages_dev, int batch, int height, int width, int hp, int wp,
+                           uint16_t* prob_dev, void* stream);
+
+/* DB post-process on device: prob -> integer quads (TL,TR,BR,BL) in page pixels.
+ * boxes_dev int32 [B][max_boxes][8], scores_dev float [B][max_boxes], counts_dev int32 [B].
+ * Output shape follows ocr_postprocessor.py:24 / ocr_service.py:295-301 (4 points / flat 8). */
+int lumina_ocr_det_postprocess(lumina_ocr_t* h, const uint16_t* prob_dev, int batch, int hp, int wp, int valid_h, int valid_w,
+                               float thresh, float box_thresh, float unclip_ratio, int min_size, int max_boxes,
+                               int32_t* boxes_dev, float* scores_dev, int32_t* counts_dev, void* stream);
+
+/* Recognition crops: for crop i, sample quad quads_dev[i] (8 int32) of page page_idx_dev[i] into
+ * crops_dev uint8 [n][32][320][3]; widths_dev int32 [n] receives the valid width. */
+int lumina_ocr_rec_crop(lumina_ocr_t* h, const uint8_t* pages_dev, int batch, int height, int width, const int32_t* quads_dev,
+                        const int32_t* page_idx_dev, int n_crops, uint8_t* crops_dev, int32_t* widths_dev, void* stream);
+
+/* CRNN (MobileNetV3-small x0.5 + 2xBiLSTM(96) + FC) with the CTC FC, arg-max and soft-max fused:
+ * crops uint8 [n][32][320][3] (+ optional valid widths) -> idx int32 [n][80], prob float [n][80]. */
+int lumina_ocr_rec_forward(lumina_ocr_t* h, const uint8_t* crops_dev, const int32_t* widths_dev, int n_crops, int32_t* idx_dev,
+                           float* prob_dev, void* stream);
+
+/* CTC greedy decode: collapse repeats, drop blank(0). text int32 [n][80] (class ids, -1 padded),
+ * len int32 [n], score float [n] (mean max-prob of kept steps) — the (text, confidence) pair of
+ * ocr_postprocessor.py:73-93 and the "confidence" key of ocr_service.py:298. */
+int lumina_ocr_ctc_decode(lumina_ocr_t* h, const int32_t* idx_dev, const float* prob_dev, int n, int32_t* text_dev, int32_t* len_dev,
+                          float* score_dev, void* stream);
+
+/* ---- kernel-level entry points (parity tests, benchmarks) ---- */
+/* Generic NHWC bf16 convolution through the MFMA implicit-GEMM kernel.  w_host: OHWI bf16 bits
+ * [cout][ks][ks][cin], bias_host float [cout]; ks/stride in {1/1, 2/2, 3/1, 3/2}; cin % 16 == 0,
+ * cout % 8 == 0; act: 0 none, 1 relu, 2 hswish, 3 hsigmoid, 4 sigmoid; res_dev optional [N,Ho,Wo,cout].
+ * Synchronous (packs and uploads the weights, runs, waits). */
+int lumina_ocr_conv2d(lumina_ocr_t* h, const uint16_t* x_dev, int n, int height, int width, int cin, const uint16_t* w_host,
+                      const float* bias_host, int cout, int ks, int stride, int act, const uint16_t* res_dev, uint16_t* y_dev,
+                      void* stream);
+/* Copy an intermediate activation of the last det/rec forward (option keep_taps=1) to host memory.
+ * dims receives n,h,w,c; returns non-zero when the tap is unknown or the buffer too small. */
+int lumina_ocr_read_tap(lumina_ocr_t* h, const char* name, uint16_t* out_host, size_t capacity_elems, int dims[4]);
+/* Sum of conv-kernel device time (ms) and algorithmic FLOPs since the last call (option time_convs=1). */
+int lumina_ocr_conv_timing(lumina_ocr_t* h, double* total_ms, double* total_flops, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,186 @@
+// extern "C" surface of liblumina_ocr.so (declared in include/lumina_ocr.h). Nothing throws.
+#include <cstring>
+#include <new>
+
+#include "../../include/lumina_ocr.h"
+#include "dbpost.h"
+#include "engine.h"
+#include "ops.h"
+#include "stem_conv.h"
+
+#define API_TRY try {
+#define API_CATCH(h)                                                             \
+    }                                                                            \
+    catch (const std::exception& e) { return locr_fail(h, "exception", e.what()); } \
+    catch (...) { return locr_fail(h, "exception", "unknown"); }
+
+extern "C" {
+
+const char* lumina_ocr_version(void) { return "lumina-ocr-mi355x 0.1 (gfx950)"; }
+
+int lumina_ocr_create(int device, lumina_ocr_t** out) {
+    if (!out) return 1;
+    *out = nullptr;
+    lumina_ocr* eng = new (std::nothrow) lumina_ocr();
+    if (!eng) return 1;
+    eng->device = device;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        eng->err = "no HIP device " + std::to_string(device) + " (device count " + std::to_string(ndev) + ")";
+        *out = eng;  // handle is returned so the caller can read the error
+        return 2;
+    }
+    if (hipSetDevice(device) != hipSuccess) { eng->err = "hipSetDevice failed"; *out = eng; return 2; }
+    *out = eng;
+    return 0;
+}
+
+void lumina_ocr_destroy(lumina_ocr_t* h) {
+    if (!h) return;
+    for (void* p : h->owned) (void)hipFree(p);
+    if (h->ws) (void)hipFree(h->ws);
+    for (auto& ev : h->conv_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    delete h;
+}
+
+const char* lumina_ocr_last_error(const lumina_ocr_t* h) { return h ? h->err.c_str() : "null handle"; }
+
+int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value) {
+    if (!h || !key) return 1;
+    if (!strcmp(key, "det_sub_batch")) h->det_sub_batch = value > 0 ? value : 1;
+    else if (!strcmp(key, "rec_sub_batch")) h->rec_sub_batch = value > 0 ? value : 1;
+    else if (!strcmp(key, "keep_taps")) h->keep_taps = value != 0;
+    else if (!strcmp(key, "time_convs")) h->time_convs = value != 0;
+    else return locr_fail(h, "set_option: unknown key", key);
+    return 0;
+}
+
+int lumina_ocr_load_det_weights(lumina_ocr_t* h, const void* blob, size_t nbytes) {
+    if (!h || !blob) return 1;
+    API_TRY return eng_load_det(h, blob, nbytes); API_CATCH(h)
+}
+int lumina_ocr_load_rec_weights(lumina_ocr_t* h, const void* blob, size_t nbytes) {
+    if (!h || !blob) return 1;
+    API_TRY return eng_load_rec(h, blob, nbytes); API_CATCH(h)
+}
+int lumina_ocr_num_classes(const lumina_ocr_t* h) { return h ? h->num_classes : 0; }
+
+int lumina_ocr_normalize(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, int hp, int wp, const float scale[3],
+                         const float shift[3], int layout_nchw, uint16_t* out_dev, void* stream) {
+    if (!h || !img_dev || !out_dev || hp < height || wp < width) return locr_fail(h, "normalize", "bad arguments");
+    hipError_t e = normalize_launch(img_dev, out_dev, n, height, width, hp, wp, height, width, scale, shift, layout_nchw, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : locr_fail(h, "normalize", hipGetErrorString(e));
+}
+
+int lumina_ocr_det_forward(lumina_ocr_t* h, const uint8_t* pages_dev, int batch, int height, int width, int hp, int wp, uint16_t* prob_dev,
+                           void* stream) {
+    if (!h || !pages_dev || !prob_dev) return locr_fail(h, "det_forward", "null argument");
+    API_TRY return eng_det_forward(h, pages_dev, batch, height, width, hp, wp, prob_dev, (hipStream_t)stream); API_CATCH(h)
+}
+
+int lumina_ocr_det_postprocess(lumina_ocr_t* h, const uint16_t* prob_dev, int batch, int hp, int wp, int valid_h, int valid_w, float thresh,
+                               float box_thresh, float unclip_ratio, int min_size, int max_boxes, int32_t* boxes_dev, float* scores_dev,
+                               int32_t* counts_dev, void* stream) {
+    if (!h || !prob_dev || !boxes_dev || !scores_dev || !counts_dev) return locr_fail(h, "det_postprocess", "null argument");
+    if (batch <= 0 || max_boxes <= 0 || valid_h > hp || valid_w > wp) return locr_fail(h, "det_postprocess", "bad dimensions");
+    API_TRY
+    // pages are processed in groups that bound the workspace
+    const int group = 8;
+    for (int b0 = 0; b0 < batch; b0 += group) {
+        const int nb = batch - b0 < group ? batch - b0 : group;
+        const size_t need = dbpost_workspace_bytes(nb, hp, wp, max_boxes);
+        if (eng_ws_reserve(h, need)) return 1;
+        DbPostParams p{};
+        p.prob = prob_dev + (size_t)b0 * hp * wp; p.B = nb; p.Hp = hp; p.Wp = wp; p.valid_h = valid_h; p.valid_w = valid_w;
+        p.thresh = thresh; p.box_thresh = box_thresh; p.unclip_ratio = unclip_ratio; p.min_size = min_size; p.max_boxes = max_boxes;
+        p.boxes = boxes_dev + (size_t)b0 * max_boxes * 8; p.scores = scores_dev + (size_t)b0 * max_boxes; p.counts = counts_dev + b0;
+        hipError_t e = dbpost_launch(p, h->ws, (hipStream_t)stream);
+        if (e != hipSuccess) return locr_fail(h, "det_postprocess", hipGetErrorString(e));
+    }
+    return 0;
+    API_CATCH(h)
+}
+
+int lumina_ocr_rec_crop(lumina_ocr_t* h, const uint8_t* pages_dev, int batch, int height, int width, const int32_t* quads_dev,
+                        const int32_t* page_idx_dev, int n_crops, uint8_t* crops_dev, int32_t* widths_dev, void* stream) {
+    if (!h || !pages_dev || !quads_dev || !page_idx_dev || !crops_dev || !widths_dev) return locr_fail(h, "rec_crop", "null argument");
+    (void)batch;
+    hipError_t e = rec_crop_launch(pages_dev, height, width, quads_dev, page_idx_dev, n_crops, crops_dev, widths_dev, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : locr_fail(h, "rec_crop", hipGetErrorString(e));
+}
+
+int lumina_ocr_rec_forward(lumina_ocr_t* h, const uint8_t* crops_dev, const int32_t* widths_dev, int n_crops, int32_t* idx_dev, float* prob_dev,
+                           void* stream) {
+    if (!h || !crops_dev || !idx_dev || !prob_dev) return locr_fail(h, "rec_forward", "null argument");
+    API_TRY return eng_rec_forward(h, crops_dev, widths_dev, n_crops, idx_dev, prob_dev, (hipStream_t)stream); API_CATCH(h)
+}
+
+int lumina_ocr_ctc_decode(lumina_ocr_t* h, const int32_t* idx_dev, const float* prob_dev, int n, int32_t* text_dev, int32_t* len_dev,
+                          float* score_dev, void* stream) {
+    if (!h || !idx_dev || !prob_dev || !text_dev || !len_dev || !score_dev) return locr_fail(h, "ctc_decode", "null argument");
+    if (n <= 0) return 0;
+    hipError_t e = ctc_collapse_launch(idx_dev, prob_dev, text_dev, len_dev, score_dev, n, LUMINA_REC_T, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : locr_fail(h, "ctc_decode", hipGetErrorString(e));
+}
+
+int lumina_ocr_conv2d(lumina_ocr_t* h, const uint16_t* x_dev, int n, int height, int width, int cin, const uint16_t* w_host,
+                      const float* bias_host, int cout, int ks, int stride, int act, const uint16_t* res_dev, uint16_t* y_dev, void* stream) {
+    if (!h || !x_dev || !w_host || !bias_host || !y_dev) return locr_fail(h, "conv2d", "null argument");
+    if (cout % 8 != 0) return locr_fail(h, "conv2d", "cout must be a multiple of 8");
+    API_TRY
+    lumina_ocr* eng = h;
+    ConvLayer L;
+    L.name = "conv2d"; L.ks = ks; L.stride = stride; L.cin = cin; L.cout = cout; L.act = act;
+    if (!conv_pick_cfg(ks, stride, cin, cout, &L.cfg)) return locr_fail(h, "conv2d", "unsupported ks/stride/cin");
+    std::vector<bf16_t> packed(conv_packed_weight_elems(cout, ks, cin, L.cfg.bn));
+    pack_conv_weights(w_host, cout, ks, cin, L.cfg.bn, L.cfg.ck, packed.data());
+    const int ntiles = (cout + L.cfg.bn - 1) / L.cfg.bn;
+    std::vector<float> bias((size_t)ntiles * L.cfg.bn, 0.f);
+    memcpy(bias.data(), bias_host, sizeof(float) * cout);
+    void *dw = nullptr, *db = nullptr;
+    if (hipMalloc(&dw, packed.size() * 2) != hipSuccess || hipMalloc(&db, bias.size() * 4) != hipSuccess) return locr_fail(h, "conv2d", "hipMalloc");
+    (void)hipMemcpy(dw, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, bias.data(), bias.size() * 4, hipMemcpyHostToDevice);
+    L.wpk = static_cast<bf16_t*>(dw); L.bias = static_cast<float*>(db);
+    Tensor4 x; x.p = const_cast<bf16_t*>(x_dev); x.n = n; x.h = height; x.w = width; x.c = cin;
+    Tensor4 y; y.p = y_dev; y.n = n; y.c = cout;
+    y.h = (ks == 3) ? (height - 1) / stride + 1 : height / stride;
+    y.w = (ks == 3) ? (width - 1) / stride + 1 : width / stride;
+    Tensor4 r; r.p = const_cast<bf16_t*>(res_dev); r.n = n; r.h = y.h; r.w = y.w; r.c = cout;
+    int rc = eng_run_conv(eng, L, x, &y, res_dev ? &r : nullptr, 0, OUT_NORMAL, 0, 0, 0, false, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(dw); (void)hipFree(db);
+    if (rc) return rc;
+    return e == hipSuccess ? 0 : locr_fail(h, "conv2d sync", hipGetErrorString(e));
+    API_CATCH(h)
+}
+
+int lumina_ocr_read_tap(lumina_ocr_t* h, const char* name, uint16_t* out_host, size_t capacity_elems, int dims[4]) {
+    if (!h || !name || !dims) return 1;
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return locr_fail(h, "read_tap: unknown tap", name);
+    const Tensor4& t = it->second;
+    dims[0] = t.n; dims[1] = t.h; dims[2] = t.w; dims[3] = t.c;
+    if (!out_host) return 0;
+    if (capacity_elems < t.elems()) return locr_fail(h, "read_tap", "buffer too small");
+    if (hipDeviceSynchronize() != hipSuccess) return locr_fail(h, "read_tap", "sync failed");
+    hipError_t e = hipMemcpy(out_host, t.p, t.elems() * sizeof(bf16_t), hipMemcpyDeviceToHost);
+    return e == hipSuccess ? 0 : locr_fail(h, "read_tap", hipGetErrorString(e));
+}
+
+int lumina_ocr_conv_timing(lumina_ocr_t* h, double* total_ms, double* total_flops, int* launches) {
+    if (!h || !total_ms || !total_flops || !launches) return 1;
+    if (hipDeviceSynchronize() != hipSuccess) return locr_fail(h, "conv_timing", "sync failed");
+    double ms = 0, fl = 0;
+    for (size_t i = 0; i < h->conv_events.size(); ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, h->conv_events[i].first, h->conv_events[i].second) == hipSuccess) ms += t;
+        fl += h->conv_flops[i];
+        (void)hipEventDestroy(h->conv_events[i].first); (void)hipEventDestroy(h->conv_events[i].second);
+    }
+    *total_ms = ms; *total_flops = fl; *launches = (int)h->conv_events.size();
+    h->conv_events.clear(); h->conv_flops.clear(); h->conv_names.clear();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// Shared device/host helpers for the Lumina OCR HIP engine (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits; all activations are NHWC bf16
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_HSIGMOID = 3, ACT_SIGMOID = 4 };
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+// round-to-nearest-even; inputs here are finite (activations), NaN handling not needed on this path
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_HSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f;
+        case ACT_HSIGMOID: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
+        case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD (round-robin
+// dispatch), so give each XCD label a contiguous range of logical ids (L2 reuse of halos/weights).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+#define LOCR_CHECK(expr)                                                        \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) return locr_fail(eng, #expr, hipGetErrorString(_e)); \
+    } while (0)

@@ -1,0 +1,41 @@
+// Host-visible description of one implicit-GEMM convolution launch (NHWC bf16, MFMA).
+#pragma once
+#include "common.h"
+
+enum ConvOutMode : int {
+    OUT_NORMAL = 0,    // y[n, oy, ox, coff + co]
+    OUT_UPSAMPLE = 1,  // nearest-neighbour replicate each output pixel f x f times (f = 1 << up_shift)
+    OUT_CONVT = 2,     // 2x2/s2 transposed conv: gemm column q*C + co -> y[n, 2oy+dy, 2ox+dx, co], q = dy*2+dx
+    OUT_CONVT1 = 3,    // same with C == 1 (probability map): gemm columns 0..3 -> 2x2 block of a 1-channel map
+};
+
+struct ConvParams {
+    const bf16_t* x;    // [N, H, W, Cin]   (Cin % 16 == 0)
+    const bf16_t* wpk;  // packed weights, see pack_conv_weights()
+    const float* bias;  // [n_tiles * BN] (zero padded)
+    const bf16_t* res;  // optional residual / top-down tensor, read at (oy >> res_shift, ox >> res_shift)
+    bf16_t* y;
+    int N, H, W, Cin;
+    int Ho, Wo;       // conv output grid
+    int Cout;         // real gemm columns (<= n_tiles * BN); chunks of 8 beyond round_up(Cout,8) are not stored
+    int y_cstride, y_coff;
+    int res_cstride, res_h, res_w, res_shift;
+    int act;
+    int out_mode, up_shift, convt_c;
+    int tiles_x, tiles_y, n_tiles;  // spatial tiles per image, cout tiles
+    int pix_limit;  // flat-GEMM mode (1x1): pixels >= pix_limit of an image are neither read nor written (0 = off)
+};
+
+struct ConvKernelCfg {
+    int ks, stride, bn, ck, tw;
+};
+
+// Size in bytes of the packed weight image for (cout, ks, cin) under cfg.
+size_t conv_packed_weight_elems(int cout_gemm, int ks, int cin, int bn);
+// Pack OHWI bf16 weights [cout_gemm][ks][ks][cin] into [ntile][chunk][plane][tap*BN + n][8].
+void pack_conv_weights(const bf16_t* ohwi, int cout_gemm, int ks, int cin, int bn, int ck, bf16_t* out);
+
+// Choose a kernel configuration for a layer; launch it. Returns hipSuccess or an error.
+bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cfg);
+hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t stream);
+const char* conv_kernel_name(const ConvKernelCfg& cfg);

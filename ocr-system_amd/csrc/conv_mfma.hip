@@ -1,0 +1,303 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4): NHWC bf16 activations, OHWI bf16 weights,
+// fp32 MFMA accumulation, fused bias + residual / top-down add + activation epilogue.
+//
+// Replaces the engine slot of the reference provider (there is no local convolution code in
+// the reference: /root/reference/backend/services/ocr_service.py:213-246 is a remote call).
+//
+// Structure (one 256-thread workgroup = 4 waves):
+//   * output tile  = TH x TW (=256) pixels  x  BN output channels; wave w owns pixel rows
+//     {2w, 2w+1} (two 32-pixel MFMA column tiles) x all BN/32 row tiles.
+//   * the K loop walks input-channel chunks of CK; per chunk the (TH-1)*S+KS x (TW-1)*S+KS
+//     input halo tile is staged ONCE in LDS and re-used by all KS*KS taps (im2col never touches
+//     HBM), together with the chunk's [tap][BN][CK] weight slab (pre-packed on the host in the
+//     exact LDS order, so its loads are fully coalesced).
+//   * LDS images are "plane" layouts: plane c holds the c-th 16-byte (8-channel) slice of every
+//     halo pixel / weight row, 16 B per entry.  A 32x32x16 MFMA fragment read (lane = pixel or
+//     cout, 8 consecutive k) is then a unit-stride ds_read_b128: conflict-free with no swizzle.
+//     The A plane stride is == 4 (mod 16) entries so the 4-lanes-per-pixel staging writes are
+//     conflict-free too.
+//   * orientation: D[cout][pixel] = W[cout][k] * X[k][pixel]  (weights are the MFMA A operand),
+//     so each lane ends up with 4 consecutive output channels of one pixel per accumulator
+//     quad -> packed 8-byte LDS staging writes -> 16-byte fully coalesced NHWC stores.
+//   * next chunk's global loads are issued into registers before the current chunk's MFMAs
+//     (async-stage split); two workgroups per CU (BN <= 64) overlap each other's barriers.
+#include "conv_mfma.h"
+
+namespace {
+
+template <int KS, int S, int BN, int CK, int TW>
+struct Cfg {
+    static constexpr int TH = 256 / TW;
+    static constexpr int PAD = (KS == 3) ? 1 : 0;
+    static constexpr int HH = (TH - 1) * S + KS;
+    static constexpr int HW = (TW - 1) * S + KS;
+    static constexpr int HWP = HW;
+    static constexpr int NPL = CK / 8;
+    static constexpr int HPX = HH * HWP;
+    static constexpr int PMOD = (NPL >= 8) ? 2 : 4;
+    static constexpr int PLANE_A = HPX + ((PMOD - HPX % 16) + 16) % 16;
+    static constexpr int TAPS = KS * KS;
+    static constexpr int WROWS = TAPS * BN;
+    static constexpr int PLANE_W = WROWS;
+    static constexpr int NT = BN / 32;
+    static constexpr int A_BYTES = PLANE_A * NPL * 16;
+    static constexpr int W_BYTES = PLANE_W * NPL * 16;
+    static constexpr int STAGE_PITCH = BN * 2 + 16;
+    static constexpr int STAGE_BYTES = 256 * STAGE_PITCH;
+    static constexpr int LDS_BYTES = (A_BYTES + W_BYTES) > STAGE_BYTES ? (A_BYTES + W_BYTES) : STAGE_BYTES;
+    static constexpr int A_ITEMS = HH * HW * NPL;
+    static constexpr int AIT = (A_ITEMS + 255) / 256;
+    static constexpr int W_ITEMS = WROWS * NPL;
+    static constexpr int WIT = (W_ITEMS + 255) / 256;
+    static constexpr int CPP = BN / 8;  // 16-byte chunks per pixel in the store pass
+};
+
+__device__ __forceinline__ bf16x8_t lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+
+template <int KS, int S, int BN, int CK, int TW>
+__global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(const ConvParams p) {
+    using C = Cfg<KS, S, BN, CK, TW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;
+    unsigned char* sW = smem + C::A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = lid % p.n_tiles;
+    const int mtile = lid / p.n_tiles;
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int n_img = mtile / tiles_per_img;
+    const int trem = mtile - n_img * tiles_per_img;
+    const int tile_y = trem / p.tiles_x, tile_x = trem - tile_y * p.tiles_x;
+
+    const bf16_t* ximg = p.x + (size_t)n_img * p.H * p.W * p.Cin;
+    const int nchunks = p.Cin / CK;
+    const bf16_t* wbase = p.wpk + (size_t)ntile * nchunks * C::W_ITEMS * 8;
+
+    // ---- per-thread staging descriptors (independent of the chunk) ----
+    int a_goff[C::AIT], a_loff[C::AIT];
+    const int iy0 = tile_y * C::TH * S - C::PAD, ix0 = tile_x * TW * S - C::PAD;
+#pragma unroll
+    for (int it = 0; it < C::AIT; ++it) {
+        const int i = tid + 256 * it;
+        const int pi = i / C::NPL, c = i - pi * C::NPL;
+        const int hy = pi / C::HW, hx = pi - hy * C::HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool item = i < C::A_ITEMS;
+        const bool inb = item && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && (p.pix_limit == 0 || iy * p.W + ix < p.pix_limit);
+        a_goff[it] = inb ? (iy * p.W + ix) * p.Cin + c * 8 : -1;
+        a_loff[it] = item ? (c * C::PLANE_A + hy * C::HWP + hx) * 16 : -1;
+    }
+
+    uint4 a_reg[C::AIT], w_reg[C::WIT];
+#define ISSUE_LOADS(chunk_)                                                                          \
+    {                                                                                                \
+        const bf16_t* xa = ximg + (chunk_) * CK;                                                     \
+        _Pragma("unroll") for (int it = 0; it < C::AIT; ++it) {                                      \
+            uint4 t_ = make_uint4(0, 0, 0, 0);                                                       \
+            if (a_goff[it] >= 0) t_ = *reinterpret_cast<const uint4*>(xa + a_goff[it]);              \
+            a_reg[it] = t_;                                                                          \
+        }                                                                                            \
+        const uint4* wsrc = reinterpret_cast<const uint4*>(wbase + (size_t)(chunk_) * C::W_ITEMS * 8); \
+        _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
+            const int i = tid + 256 * it;                                                            \
+            uint4 t_ = make_uint4(0, 0, 0, 0);                                                       \
+            if (C::W_ITEMS % 256 == 0 || i < C::W_ITEMS) t_ = wsrc[i];                               \
+            w_reg[it] = t_;                                                                          \
+        }                                                                                            \
+    }
+#define WRITE_LDS()                                                                                  \
+    {                                                                                                \
+        _Pragma("unroll") for (int it = 0; it < C::AIT; ++it)                                        \
+            if (a_loff[it] >= 0) *reinterpret_cast<uint4*>(sA + a_loff[it]) = a_reg[it];             \
+        _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
+            const int i = tid + 256 * it;                                                            \
+            if (C::W_ITEMS % 256 == 0 || i < C::W_ITEMS) *reinterpret_cast<uint4*>(sW + i * 16) = w_reg[it]; \
+        }                                                                                            \
+    }
+
+    f32x16_t acc[2][C::NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+
+    // fragment read bases (bytes)
+    int aoff[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int ty = wave * 2 + mt, tx = r;  // TW == 32
+        aoff[mt] = (h * C::PLANE_A + (ty * S) * C::HWP + tx * S) * 16;
+    }
+    const int woff = (h * C::PLANE_W + r) * 16;
+
+    ISSUE_LOADS(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();
+        WRITE_LDS();
+        __syncthreads();
+        if (chunk + 1 < nchunks) ISSUE_LOADS(chunk + 1);
+#pragma unroll
+        for (int tap = 0; tap < C::TAPS; ++tap) {
+            const int kh = tap / KS, kw = tap - kh * KS;
+#pragma unroll
+            for (int kc = 0; kc < CK / 16; ++kc) {
+                bf16x8_t bfr[2], afr[C::NT];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    bfr[mt] = lds_frag(sA + aoff[mt] + ((2 * kc) * C::PLANE_A + kh * C::HWP + kw) * 16);
+#pragma unroll
+                for (int nt = 0; nt < C::NT; ++nt)
+                    afr[nt] = lds_frag(sW + woff + ((2 * kc) * C::PLANE_W + tap * BN + nt * 32) * 16);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < C::NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[nt], bfr[mt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---------------- epilogue: bias + residual + act -> bf16 -> LDS stage -> coalesced store ----------------
+    __syncthreads();
+    unsigned char* stage = smem;
+    const int cout_r8 = (p.Cout + 7) & ~7;
+    const float* bptr = p.bias + ntile * BN;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int ty = wave * 2 + mt, tx = r;
+        const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
+        const bool pvalid = oy < p.Ho && ox < p.Wo && (p.pix_limit == 0 || oy * p.Wo + ox < p.pix_limit);
+        const int tp = ty * TW + tx;
+        const bf16_t* rrow = nullptr;
+        if (p.res != nullptr && pvalid)
+            rrow = p.res + (((size_t)n_img * p.res_h + (oy >> p.res_shift)) * p.res_w + (ox >> p.res_shift)) * p.res_cstride + ntile * BN;
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cn = nt * 32 + 8 * g + 4 * h;
+                const float4 b4 = *reinterpret_cast<const float4*>(bptr + cn);
+                float v0 = acc[mt][nt][4 * g + 0] + b4.x, v1 = acc[mt][nt][4 * g + 1] + b4.y;
+                float v2 = acc[mt][nt][4 * g + 2] + b4.z, v3 = acc[mt][nt][4 * g + 3] + b4.w;
+                if (rrow != nullptr && ntile * BN + cn < cout_r8) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(rrow + cn);
+                    v0 += __uint_as_float(rv.x << 16); v1 += __uint_as_float(rv.x & 0xFFFF0000u);
+                    v2 += __uint_as_float(rv.y << 16); v3 += __uint_as_float(rv.y & 0xFFFF0000u);
+                }
+                v0 = apply_act(v0, p.act); v1 = apply_act(v1, p.act);
+                v2 = apply_act(v2, p.act); v3 = apply_act(v3, p.act);
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(stage + tp * C::STAGE_PITCH + cn * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < C::CPP; ++k) {
+        const int i = tid + 256 * k;
+        const int tp = i / C::CPP, ch = i - tp * C::CPP;
+        const int ty = tp / TW, tx = tp - ty * TW;
+        const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
+        const int co = ntile * BN + ch * 8;
+        if (oy >= p.Ho || ox >= p.Wo || co >= cout_r8 || (p.pix_limit != 0 && oy * p.Wo + ox >= p.pix_limit)) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + tp * C::STAGE_PITCH + ch * 16);
+        if (p.out_mode == OUT_NORMAL) {
+            bf16_t* dst = p.y + (((size_t)n_img * p.Ho + oy) * p.Wo + ox) * p.y_cstride + p.y_coff + co;
+            *reinterpret_cast<uint4*>(dst) = v;
+        } else if (p.out_mode == OUT_UPSAMPLE) {
+            const int f = 1 << p.up_shift;
+            const int HoU = p.Ho << p.up_shift, WoU = p.Wo << p.up_shift;
+            for (int dy = 0; dy < f; ++dy)
+                for (int dx = 0; dx < f; ++dx) {
+                    bf16_t* dst = p.y + (((size_t)n_img * HoU + (oy * f + dy)) * WoU + (ox * f + dx)) * p.y_cstride + p.y_coff + co;
+                    *reinterpret_cast<uint4*>(dst) = v;
+                }
+        } else if (p.out_mode == OUT_CONVT) {
+            const int q = co / p.convt_c, cc = co - q * p.convt_c;
+            const int yy = 2 * oy + (q >> 1), xx = 2 * ox + (q & 1);
+            bf16_t* dst = p.y + (((size_t)n_img * (2 * p.Ho) + yy) * (2 * p.Wo) + xx) * p.y_cstride + p.y_coff + cc;
+            *reinterpret_cast<uint4*>(dst) = v;
+        } else {  // OUT_CONVT1: columns 0..3 = 2x2 block of a single-channel map
+            if (ch == 0) {
+                bf16_t* dst = p.y + ((size_t)n_img * (2 * p.Ho) + 2 * oy) * (size_t)(2 * p.Wo) + 2 * ox;
+                *reinterpret_cast<uint32_t*>(dst) = v.x;
+                *reinterpret_cast<uint32_t*>(dst + 2 * p.Wo) = v.y;
+            }
+        }
+    }
+}
+
+template <int KS, int S, int BN, int CK, int TW>
+hipError_t launch_t(const ConvParams& p, hipStream_t stream) {
+    using C = Cfg<KS, S, BN, CK, TW>;
+    auto kern = conv_mfma_kernel<KS, S, BN, CK, TW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int grid = p.N * p.tiles_x * p.tiles_y * p.n_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t conv_packed_weight_elems(int cout_gemm, int ks, int cin, int bn) {
+    const int ntiles = (cout_gemm + bn - 1) / bn;
+    return (size_t)ntiles * bn * ks * ks * cin;
+}
+
+void pack_conv_weights(const bf16_t* ohwi, int cout_gemm, int ks, int cin, int bn, int ck, bf16_t* out) {
+    const int ntiles = (cout_gemm + bn - 1) / bn, taps = ks * ks, npl = ck / 8, nchunks = cin / ck;
+    const size_t wrows = (size_t)taps * bn;
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int chunk = 0; chunk < nchunks; ++chunk)
+            for (int c = 0; c < npl; ++c)
+                for (int tap = 0; tap < taps; ++tap)
+                    for (int n = 0; n < bn; ++n) {
+                        const int co = nt * bn + n;
+                        bf16_t* dst = out + ((((size_t)nt * nchunks + chunk) * npl + c) * wrows + (size_t)tap * bn + n) * 8;
+                        for (int j = 0; j < 8; ++j)
+                            dst[j] = co < cout_gemm ? ohwi[((size_t)co * taps + tap) * cin + chunk * ck + c * 8 + j] : (bf16_t)0;
+                    }
+}
+
+bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cfg) {
+    if (!((ks == 1 && stride == 1) || (ks == 2 && stride == 2) || (ks == 3 && (stride == 1 || stride == 2)))) return false;
+    if (cin % 16 != 0) return false;
+    cfg->ks = ks; cfg->stride = stride; cfg->tw = 32;
+    cfg->ck = (cin % 32 == 0) ? 32 : 16;
+    cfg->bn = cout_gemm <= 32 ? 32 : (cout_gemm <= 64 ? 64 : 128);
+    if (ks == 3 && stride == 2 && cfg->bn == 128 && cfg->ck == 32) cfg->bn = 64;  // halo tile is 4x larger: keep LDS < 160 KB
+    return true;
+}
+
+const char* conv_kernel_name(const ConvKernelCfg& c) {
+    static thread_local char buf[64];
+    snprintf(buf, sizeof(buf), "conv_mfma<k%d,s%d,bn%d,ck%d>", c.ks, c.stride, c.bn, c.ck);
+    return buf;
+}
+
+#define DISPATCH(KS_, S_, BN_, CK_)                                                             \
+    if (cfg.ks == KS_ && cfg.stride == S_ && cfg.bn == BN_ && cfg.ck == CK_) return launch_t<KS_, S_, BN_, CK_, 32>(p, stream);
+
+hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t stream) {
+    p.tiles_x = ceil_div(p.Wo, 32);
+    p.tiles_y = ceil_div(p.Ho, 8);
+    p.n_tiles = ceil_div(p.Cout, cfg.bn);
+    DISPATCH(3, 1, 32, 32) DISPATCH(3, 1, 64, 32) DISPATCH(3, 1, 128, 32)
+    DISPATCH(3, 2, 32, 32) DISPATCH(3, 2, 64, 32)
+    DISPATCH(1, 1, 32, 32) DISPATCH(1, 1, 64, 32) DISPATCH(1, 1, 128, 32)
+    DISPATCH(1, 1, 32, 16) DISPATCH(1, 1, 64, 16) DISPATCH(1, 1, 128, 16)
+    DISPATCH(2, 2, 32, 32) DISPATCH(2, 2, 64, 32) DISPATCH(2, 2, 128, 32)
+    return hipErrorInvalidValue;
+}

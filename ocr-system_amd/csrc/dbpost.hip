@@ -1,0 +1,533 @@
+// DB post-process and recognition crop on the GPU (gfx950), bit-identical by construction to the
+// sequential definition in oracle/csrc/dbpost_oracle.c (integer geometry, exact rational area
+// comparison, fixed-point score sum, correctly-rounded fp64 corner arithmetic, no fma).
+//
+// No reference counterpart; output shape = the 4-point quad of
+// /root/reference/backend/utils/ocr_postprocessor.py:24 / flat polygon of ocr_service.py:295-301.
+//
+// Pipeline (all stream-ordered kernels, no host round trip):
+//   1 ccl_init      one wave per page row: threshold -> label = index of the run start (or -1)
+//   2 ccl_merge     per pixel: union-find (atomicMin) links to the row above (8-connectivity)
+//   3 ccl_compress  label = root = smallest linear index of the component (canonical)
+//   4 root_count / root_scan / root_assign : roots in raster order -> component id k < max_boxes
+//   5 comp_extent   per pixel: atomicMin/Max of the component's y range
+//   6 seg_scan      per page: row-extreme segments; 7 row_extremes: per-row min/max x (atomics)
+//   8 comp_box      one wave per component: hull (monotone chains), rotating calipers over hull
+//                   edges (lanes = edges), fixed-point score (lanes = pixels), unclip, corner order
+//   9 compact       valid boxes in component order -> boxes / scores / count
+#include "dbpost.h"
+
+namespace {
+
+__device__ __forceinline__ int uf_find(const int* L, int i) {
+    int p = L[i];
+    while (p != i) { i = p; p = L[i]; }
+    return i;
+}
+__device__ __forceinline__ void uf_union(int* L, int a, int b) {
+    bool done = false;
+    while (!done) {
+        a = uf_find(L, a); b = uf_find(L, b);
+        if (a < b) { const int old = atomicMin(&L[b], a); done = (old == b); b = old; }
+        else if (b < a) { const int old = atomicMin(&L[a], b); done = (old == a); a = old; }
+        else done = true;
+    }
+}
+
+// ---- 1: one wave per (page,row) ----
+__global__ __launch_bounds__(64) void ccl_init_kernel(const bf16_t* prob, int* label, int Hp, int Wp, int vh, int vw, float thresh) {
+    const int row = blockIdx.x % Hp, pg = blockIdx.x / Hp, lane = threadIdx.x;
+    const size_t base = ((size_t)pg * Hp + row) * Wp;
+    int carry = -1;  // run start (x) continuing from the previous chunk, -1 = none
+    for (int x0 = 0; x0 < Wp; x0 += 64) {
+        const int x = x0 + lane;
+        const bool fg = x < vw && row < vh && bf16_to_f32(prob[base + x]) > thresh;
+        const unsigned long long m = __ballot(fg);
+        const unsigned long long below = (~m) & ((1ull << lane) - 1ull);  // background lanes below me
+        int start;
+        if (below) start = x0 + (63 - __clzll(below)) + 1;
+        else start = carry >= 0 ? carry : x0;
+        if (x < Wp) label[base + x] = fg ? (int)(row * Wp + start) : -1;
+        // carry for next chunk: if lane 63 is fg, its run start
+        const int s63 = __shfl(start, 63);
+        carry = (m >> 63) ? s63 : -1;
+    }
+}
+
+// ---- 2 ----
+__global__ void ccl_merge_kernel(int* label, int B, int Hp, int Wp, int vh, int vw) {
+    const size_t per = (size_t)Hp * Wp, total = per * B;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const int pg = (int)(g / per);
+        const int i = (int)(g - (size_t)pg * per);
+        const int y = i / Wp, x = i - y * Wp;
+        if (y == 0 || y >= vh || x >= vw) continue;
+        int* L = label + (size_t)pg * per;
+        if (L[i] < 0) continue;
+        const bool n = L[i - Wp] >= 0;
+        const bool w = x > 0 && L[i - 1] >= 0;
+        const bool nw = x > 0 && L[i - Wp - 1] >= 0;
+        const bool ne = x + 1 < vw && L[i - Wp + 1] >= 0;
+        if (n) { if (!(w && nw)) uf_union(L, i, i - Wp); }
+        else {
+            if (ne) uf_union(L, i, i - Wp + 1);
+            if (nw && !w) uf_union(L, i, i - Wp - 1);
+        }
+    }
+}
+
+// ---- 3 ----
+__global__ void ccl_compress_kernel(int* label, int B, int Hp, int Wp) {
+    const size_t per = (size_t)Hp * Wp, total = per * B;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const int pg = (int)(g / per);
+        const int i = (int)(g - (size_t)pg * per);
+        int* L = label + (size_t)pg * per;
+        if (L[i] >= 0) L[i] = uf_find(L, i);
+    }
+}
+
+// ---- 4a: roots per row ----
+__global__ __launch_bounds__(64) void root_count_kernel(const int* label, int* rowcnt, int Hp, int Wp) {
+    const int row = blockIdx.x % Hp, pg = blockIdx.x / Hp, lane = threadIdx.x;
+    const size_t base = ((size_t)pg * Hp + row) * Wp;
+    int cnt = 0;
+    for (int x0 = 0; x0 < Wp; x0 += 64) {
+        const int x = x0 + lane;
+        const bool root = x < Wp && label[base + x] == row * Wp + x;
+        cnt += __popcll(__ballot(root));
+    }
+    if (lane == 0) rowcnt[(size_t)pg * Hp + row] = cnt;
+}
+// ---- 4b: exclusive scan per page (one wave, chunked) ----
+__global__ __launch_bounds__(64) void root_scan_kernel(int* rowcnt, int* ncomp, int Hp) {
+    const int pg = blockIdx.x, lane = threadIdx.x;
+    int* rc = rowcnt + (size_t)pg * Hp;
+    int run = 0;
+    for (int r0 = 0; r0 < Hp; r0 += 64) {
+        const int r = r0 + lane;
+        const int v = r < Hp ? rc[r] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (r < Hp) rc[r] = run + inc - v;
+        run += __shfl(inc, 63);
+    }
+    if (lane == 0) ncomp[pg] = run;
+}
+// ---- 4c: ordered ids; cid[root pixel] = k (or -1 beyond the cap); per-component init ----
+__global__ __launch_bounds__(64) void root_assign_kernel(const int* label, const int* rowoff, int* cid, int* comp_root, int* ymin, int* ymax,
+                                                          int Hp, int Wp, int maxc) {
+    const int row = blockIdx.x % Hp, pg = blockIdx.x / Hp, lane = threadIdx.x;
+    const size_t base = ((size_t)pg * Hp + row) * Wp;
+    int k0 = rowoff[(size_t)pg * Hp + row];
+    for (int x0 = 0; x0 < Wp; x0 += 64) {
+        const int x = x0 + lane;
+        const bool root = x < Wp && label[base + x] == row * Wp + x;
+        const unsigned long long m = __ballot(root);
+        if (root) {
+            const int k = k0 + __popcll(m & ((1ull << lane) - 1ull));
+            if (k < maxc) {
+                cid[base + x] = k;
+                comp_root[(size_t)pg * maxc + k] = row * Wp + x;
+                ymin[(size_t)pg * maxc + k] = 0x7fffffff;
+                ymax[(size_t)pg * maxc + k] = -1;
+            } else cid[base + x] = -1;
+        }
+        k0 += __popcll(m);
+    }
+}
+// ---- 5 ----
+__global__ void comp_extent_kernel(const int* label, const int* cid, int* ymin, int* ymax, int B, int Hp, int Wp, int maxc) {
+    const size_t per = (size_t)Hp * Wp, total = per * B;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const int pg = (int)(g / per);
+        const int i = (int)(g - (size_t)pg * per);
+        const int r = label[g];
+        if (r < 0) continue;
+        const int x = i % Wp;
+        // only run starts contribute (one atomic per run)
+        if (x > 0 && label[g - 1] >= 0) continue;
+        const int k = cid[(size_t)pg * per + r];
+        if (k < 0) continue;
+        const int y = i / Wp;
+        atomicMin(&ymin[(size_t)pg * maxc + k], y);
+        atomicMax(&ymax[(size_t)pg * maxc + k], y);
+    }
+}
+// ---- 6: per page segment offsets (one wave) + init of the segments ----
+__global__ __launch_bounds__(64) void seg_scan_kernel(const int* ncomp, const int* ymin, const int* ymax, int* segoff, int maxc) {
+    const int pg = blockIdx.x, lane = threadIdx.x;
+    const int n = ncomp[pg] < maxc ? ncomp[pg] : maxc;
+    int run = 0;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        const int v = k < n ? (ymax[(size_t)pg * maxc + k] - ymin[(size_t)pg * maxc + k] + 1) : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (k < n) segoff[(size_t)pg * (maxc + 1) + k] = run + inc - v;
+        run += __shfl(inc, 63);
+    }
+    if (lane == 0) segoff[(size_t)pg * (maxc + 1) + n] = run;
+}
+__global__ void seg_init_kernel(int* rowmin, int* rowmax, size_t total) {
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        rowmin[g] = 0x7fffffff; rowmax[g] = -1;
+    }
+}
+// ---- 7 ----
+__global__ void row_extremes_kernel(const int* label, const int* cid, const int* ymin, const int* segoff, int* rowmin, int* rowmax,
+                                    int B, int Hp, int Wp, int vw, int maxc, size_t seg_cap) {
+    const size_t per = (size_t)Hp * Wp, total = per * B;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const int pg = (int)(g / per);
+        const int i = (int)(g - (size_t)pg * per);
+        const int r = label[g];
+        if (r < 0) continue;
+        const int y = i / Wp, x = i - y * Wp;
+        const bool start = !(x > 0 && label[g - 1] >= 0);
+        const bool end = !(x + 1 < vw && label[g + 1] >= 0);
+        if (!start && !end) continue;
+        const int k = cid[(size_t)pg * per + r];
+        if (k < 0) continue;
+        const size_t s = (size_t)pg * seg_cap + segoff[(size_t)pg * (maxc + 1) + k] + (y - ymin[(size_t)pg * maxc + k]);
+        if (start) atomicMin(&rowmin[s], x);
+        if (end) atomicMax(&rowmax[s], x);
+    }
+}
+
+// ---- 8: one wave per component ----
+struct Cand { long long dx, dy, mind, maxd, minn, maxn, L, A; int have; };
+
+__device__ __forceinline__ bool frac_less(unsigned long long a1, unsigned long long l2, unsigned long long a2, unsigned long long l1, bool* eq) {
+    // compare a1*l2 vs a2*l1 exactly (128-bit)
+    const unsigned long long h1 = __umul64hi(a1, l2), lo1 = a1 * l2, h2 = __umul64hi(a2, l1), lo2 = a2 * l1;
+    *eq = (h1 == h2 && lo1 == lo2);
+    return h1 < h2 || (h1 == h2 && lo1 < lo2);
+}
+__device__ __forceinline__ bool cand_better(const Cand& a, const Cand& b) {  // is a strictly better than b
+    if (!a.have) return false;
+    if (!b.have) return true;
+    bool eq;
+    const bool less = frac_less((unsigned long long)a.A, (unsigned long long)b.L, (unsigned long long)b.A, (unsigned long long)a.L, &eq);
+    if (!eq) return less;
+    return a.dx < b.dx || (a.dx == b.dx && a.dy < b.dy);
+}
+__device__ __forceinline__ long long gcdll(long long a, long long b) {
+    a = a < 0 ? -a : a; b = b < 0 ? -b : b;
+    while (b) { const long long t = a % b; a = b; b = t; }
+    return a;
+}
+__device__ __forceinline__ long long shfl_ll(long long v, int src) {
+    const int lo = __shfl((int)(v & 0xffffffffll), src), hi = __shfl((int)(v >> 32), src);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ long long shfl_xor_ll(long long v, int m) {
+    const int lo = __shfl_xor((int)(v & 0xffffffffll), m), hi = __shfl_xor((int)(v >> 32), m);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+__global__ __launch_bounds__(64) void comp_box_kernel(const bf16_t* prob, const int* ncomp, const int* ymin, const int* ymax, const int* segoff,
+                                                      const int* rowmin, const int* rowmax, int2* hullbuf, int* box_tmp, float* score_tmp,
+                                                      int* valid_tmp, int Hp, int Wp, int vh, int vw, int maxc, size_t seg_cap,
+                                                      float box_thresh, float unclip_ratio, int min_size) {
+    const int pg = blockIdx.x / maxc, k = blockIdx.x % maxc, lane = threadIdx.x;
+    int* vflag = valid_tmp + (size_t)pg * maxc + k;
+    const int n = ncomp[pg] < maxc ? ncomp[pg] : maxc;
+    if (k >= n) { if (lane == 0) *vflag = 0; return; }
+    const int y0 = ymin[(size_t)pg * maxc + k], y1 = ymax[(size_t)pg * maxc + k];
+    const size_t seg = (size_t)pg * seg_cap + segoff[(size_t)pg * (maxc + 1) + k];
+    const int* rmin = rowmin + seg;
+    const int* rmax = rowmax + seg;
+    int2* hull = hullbuf + 2 * seg;  // capacity 2*(rows)
+    const int rows = y1 - y0 + 1;
+    __shared__ int s_nh;
+    // ---- hull: lane 0 builds the left chain in hull[0..], lane 32 builds the right chain in hull[rows..] ----
+    __shared__ int s_nl, s_nr;
+    if (lane == 0 || lane == 32) {
+        const bool left = lane == 0;
+        int2* ch = hull + (left ? 0 : rows);
+        int nc = 0;
+        for (int t = 0; t < rows; ++t) {
+            const int r = left ? t : rows - 1 - t;
+            const int2 p = make_int2(left ? rmin[r] : rmax[r], y0 + r);
+            while (nc >= 2) {
+                const int2 o = ch[nc - 2], a = ch[nc - 1];
+                const long long cr = (long long)(a.x - o.x) * (p.y - o.y) - (long long)(a.y - o.y) * (p.x - o.x);
+                if (cr >= 0) --nc; else break;
+            }
+            ch[nc++] = p;
+        }
+        if (left) s_nl = nc; else s_nr = nc;
+    }
+    __syncthreads();
+    if (lane == 0) {  // splice: left chain then right chain, dropping duplicated joints
+        int nh = s_nl;
+        const int2* rc = hull + rows;
+        for (int t = 0; t < s_nr; ++t) {
+            const int2 p = rc[t];
+            if (nh && hull[nh - 1].x == p.x && hull[nh - 1].y == p.y) continue;
+            hull[nh++] = p;
+        }
+        if (nh > 1 && hull[0].x == hull[nh - 1].x && hull[0].y == hull[nh - 1].y) --nh;
+        s_nh = nh;
+    }
+    __syncthreads();
+    const int nh = s_nh;
+    if (nh < 2) { if (lane == 0) *vflag = 0; return; }
+    // ---- calipers: lanes = edges ----
+    Cand best; best.have = 0; best.dx = best.dy = best.mind = best.maxd = best.minn = best.maxn = 0; best.L = 1; best.A = 0;
+    for (int e = lane; e < nh; e += 64) {
+        const int2 a = hull[e], b = hull[(e + 1) % nh];
+        long long dx = b.x - a.x, dy = b.y - a.y;
+        if (dx == 0 && dy == 0) continue;
+        const long long g = gcdll(dx, dy);
+        dx /= g; dy /= g;
+        if (dx < 0 || (dx == 0 && dy < 0)) { dx = -dx; dy = -dy; }
+        long long mind = 0x7fffffffffffffffll, maxd = -0x7fffffffffffffffll - 1, minn = mind, maxn = maxd;
+        for (int t = 0; t < nh; ++t) {
+            const int2 q = hull[t];
+            const long long pd = (long long)q.x * dx + (long long)q.y * dy, pn = -(long long)q.x * dy + (long long)q.y * dx;
+            mind = pd < mind ? pd : mind; maxd = pd > maxd ? pd : maxd;
+            minn = pn < minn ? pn : minn; maxn = pn > maxn ? pn : maxn;
+        }
+        Cand c; c.have = 1; c.dx = dx; c.dy = dy; c.mind = mind; c.maxd = maxd; c.minn = minn; c.maxn = maxn;
+        c.L = dx * dx + dy * dy; c.A = (maxd - mind) * (maxn - minn);
+        if (cand_better(c, best)) best = c;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        Cand o;
+        o.have = __shfl_xor(best.have, m);
+        o.dx = shfl_xor_ll(best.dx, m); o.dy = shfl_xor_ll(best.dy, m);
+        o.mind = shfl_xor_ll(best.mind, m); o.maxd = shfl_xor_ll(best.maxd, m);
+        o.minn = shfl_xor_ll(best.minn, m); o.maxn = shfl_xor_ll(best.maxn, m);
+        o.L = shfl_xor_ll(best.L, m); o.A = shfl_xor_ll(best.A, m);
+        if (cand_better(o, best)) best = o;
+    }
+    if (!best.have) { if (lane == 0) *vflag = 0; return; }
+    const long long wd = best.maxd - best.mind, wn = best.maxn - best.minn;
+    const double sqL = __dsqrt_rn((double)best.L);
+    const double sside = (double)(wd < wn ? wd : wn) / sqL;
+    if (sside < (double)min_size) { if (lane == 0) *vflag = 0; return; }
+    // ---- score: integer pixels inside the closed rectangle ----
+    double fx0, fx1, fy0, fy1;
+    {
+        const long long as[4] = {best.mind, best.maxd, best.maxd, best.mind}, bs[4] = {best.minn, best.minn, best.maxn, best.maxn};
+        double cx[4], cy[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            cx[t] = (double)(as[t] * best.dx - bs[t] * best.dy) / (double)best.L;
+            cy[t] = (double)(as[t] * best.dy + bs[t] * best.dx) / (double)best.L;
+        }
+        fx0 = fx1 = cx[0]; fy0 = fy1 = cy[0];
+#pragma unroll
+        for (int t = 1; t < 4; ++t) { fx0 = fmin(fx0, cx[t]); fx1 = fmax(fx1, cx[t]); fy0 = fmin(fy0, cy[t]); fy1 = fmax(fy1, cy[t]); }
+    }
+    int bx0 = (int)floor(fx0) - 1, bx1 = (int)ceil(fx1) + 1, by0 = (int)floor(fy0) - 1, by1 = (int)ceil(fy1) + 1;
+    bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0; bx1 = bx1 > vw - 1 ? vw - 1 : bx1; by1 = by1 > vh - 1 ? vh - 1 : by1;
+    unsigned long long sum = 0, cnt = 0;
+    const int bw = bx1 - bx0 + 1;
+    const long long npx = (long long)bw * (by1 - by0 + 1);
+    const bf16_t* pp = prob + (size_t)pg * Hp * Wp;
+    for (long long t = lane; t < npx; t += 64) {
+        const int y = by0 + (int)(t / bw), x = bx0 + (int)(t % bw);
+        const long long pd = (long long)x * best.dx + (long long)y * best.dy, pn = -(long long)x * best.dy + (long long)y * best.dx;
+        if (pd < best.mind || pd > best.maxd || pn < best.minn || pn > best.maxn) continue;
+        sum += (unsigned long long)(bf16_to_f32(pp[(size_t)y * Wp + x]) * 16777216.0f);
+        ++cnt;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { sum += (unsigned long long)shfl_xor_ll((long long)sum, m); cnt += (unsigned long long)shfl_xor_ll((long long)cnt, m); }
+    if (lane != 0) return;
+    if (!cnt) { *vflag = 0; return; }
+    const double score = ((double)sum / (double)cnt) / 16777216.0;
+    if (score < (double)box_thresh) { *vflag = 0; return; }
+    // ---- unclip + corners ----
+    const double E = ((double)unclip_ratio * (double)(wd * wn)) / (double)(2 * (wd + wn));
+    const double sside2 = ((double)(wd < wn ? wd : wn) + 2.0 * E) / sqL;
+    if (sside2 < (double)(min_size + 2)) { *vflag = 0; return; }
+    const double a0 = (double)best.mind - E, a1 = (double)best.maxd + E, b0 = (double)best.minn - E, b1 = (double)best.maxn + E;
+    double qx[4], qy[4];
+    {
+        const double as[4] = {a0, a1, a1, a0}, bs[4] = {b0, b0, b1, b1};
+        const double ddx = (double)best.dx, ddy = (double)best.dy, dL = (double)best.L;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double t1 = __dmul_rn(as[t], ddx), t2 = __dmul_rn(bs[t], ddy), t3 = __dmul_rn(as[t], ddy), t4 = __dmul_rn(bs[t], ddx);
+            qx[t] = __ddiv_rn(__dsub_rn(t1, t2), dL);
+            qy[t] = __ddiv_rn(__dadd_rn(t3, t4), dL);
+        }
+    }
+    // sort 4 points by (x, y)
+    for (int i = 1; i < 4; ++i)
+        for (int j = i; j > 0; --j) {
+            const bool lt = qx[j] < qx[j - 1] || (qx[j] == qx[j - 1] && qy[j] < qy[j - 1]);
+            if (!lt) break;
+            const double tx = qx[j], ty = qy[j]; qx[j] = qx[j - 1]; qy[j] = qy[j - 1]; qx[j - 1] = tx; qy[j - 1] = ty;
+        }
+    double ox[4], oy[4];  // TL, TR, BR, BL
+    if (qy[0] <= qy[1]) { ox[0] = qx[0]; oy[0] = qy[0]; ox[3] = qx[1]; oy[3] = qy[1]; } else { ox[0] = qx[1]; oy[0] = qy[1]; ox[3] = qx[0]; oy[3] = qy[0]; }
+    if (qy[2] <= qy[3]) { ox[1] = qx[2]; oy[1] = qy[2]; ox[2] = qx[3]; oy[2] = qy[3]; } else { ox[1] = qx[3]; oy[1] = qy[3]; ox[2] = qx[2]; oy[2] = qy[2]; }
+    int out[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        double rx = rint(ox[t]), ry = rint(oy[t]);
+        rx = rx < 0 ? 0 : rx; rx = rx > vw ? vw : rx; ry = ry < 0 ? 0 : ry; ry = ry > vh ? vh : ry;
+        out[2 * t] = (int)rx; out[2 * t + 1] = (int)ry;
+    }
+    {
+        const double wx = (double)(out[0] - out[2]), wy = (double)(out[1] - out[3]);
+        const double hx = (double)(out[0] - out[6]), hy = (double)(out[1] - out[7]);
+        const int rw = (int)sqrt(__dadd_rn(__dmul_rn(wx, wx), __dmul_rn(wy, wy))), rh = (int)sqrt(__dadd_rn(__dmul_rn(hx, hx), __dmul_rn(hy, hy)));
+        if (rw <= 3 || rh <= 3) { *vflag = 0; return; }
+    }
+    int* bo = box_tmp + ((size_t)pg * maxc + k) * 8;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bo[t] = out[t];
+    score_tmp[(size_t)pg * maxc + k] = (float)score;
+    *vflag = 1;
+}
+
+// ---- 9 ----
+__global__ __launch_bounds__(64) void compact_kernel(const int* box_tmp, const float* score_tmp, const int* valid_tmp, int* boxes, float* scores,
+                                                     int* counts, int maxc) {
+    const int pg = blockIdx.x, lane = threadIdx.x;
+    int run = 0;
+    for (int k0 = 0; k0 < maxc; k0 += 64) {
+        const int k = k0 + lane;
+        const bool v = k < maxc && valid_tmp[(size_t)pg * maxc + k] != 0;
+        const unsigned long long m = __ballot(v);
+        if (v) {
+            const int pos = run + __popcll(m & ((1ull << lane) - 1ull));
+#pragma unroll
+            for (int t = 0; t < 8; ++t) boxes[((size_t)pg * maxc + pos) * 8 + t] = box_tmp[((size_t)pg * maxc + k) * 8 + t];
+            scores[(size_t)pg * maxc + pos] = score_tmp[(size_t)pg * maxc + k];
+        }
+        run += __popcll(m);
+    }
+    if (lane == 0) counts[pg] = run;
+}
+
+// ---- recognition crop: one block per crop, threads over (row, col) ----
+__global__ __launch_bounds__(256) void rec_crop_kernel(const uint8_t* pages, int H, int W, const int* quads, const int* page_idx, uint8_t* crops,
+                                                       int* widths) {
+    const int ci = blockIdx.x, tid = threadIdx.x;
+    long long p[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { p[t][0] = quads[(size_t)ci * 8 + 2 * t]; p[t][1] = quads[(size_t)ci * 8 + 2 * t + 1]; }
+#define D2(a, b) ((p[a][0] - p[b][0]) * (p[a][0] - p[b][0]) + (p[a][1] - p[b][1]) * (p[a][1] - p[b][1]))
+    long long cw2 = D2(1, 0) > D2(2, 3) ? D2(1, 0) : D2(2, 3);
+    long long ch2 = D2(3, 0) > D2(2, 1) ? D2(3, 0) : D2(2, 1);
+#undef D2
+    if (4 * ch2 >= 9 * cw2) {
+        const long long t0 = p[0][0], t1 = p[0][1];
+        p[0][0] = p[1][0]; p[0][1] = p[1][1]; p[1][0] = p[2][0]; p[1][1] = p[2][1];
+        p[2][0] = p[3][0]; p[2][1] = p[3][1]; p[3][0] = t0; p[3][1] = t1;
+        const long long t = cw2; cw2 = ch2; ch2 = t;
+    }
+    uint8_t* out = crops + (size_t)ci * 32 * 320 * 3;
+    int wc = 0;
+    if (ch2 != 0 && cw2 != 0) {
+        const double ratio = sqrt(__ddiv_rn((double)cw2, (double)ch2));
+        wc = (int)ceil(__dmul_rn(32.0, ratio));
+        wc = wc < 1 ? 1 : (wc > 320 ? 320 : wc);
+    }
+    if (tid == 0) widths[ci] = wc;
+    const uint8_t* page = pages + (size_t)page_idx[ci] * H * W * 3;
+    const float tlx = (float)p[0][0], tly = (float)p[0][1];
+    const float ex = (float)(p[1][0] - p[0][0]), ey = (float)(p[1][1] - p[0][1]);
+    const float fx = (float)(p[3][0] - p[0][0]), fy = (float)(p[3][1] - p[0][1]);
+    for (int t = tid; t < 32 * 320; t += 256) {
+        const int i = t / 320, j = t - i * 320;
+        uint8_t r3[3] = {0, 0, 0};
+        if (j < wc) {
+            const float u = __fdiv_rn((float)j + 0.5f, (float)wc), v = __fdiv_rn((float)i + 0.5f, 32.0f);
+            const float t1 = __fmul_rn(u, ex), t2 = __fmul_rn(v, fx), t3 = __fmul_rn(u, ey), t4 = __fmul_rn(v, fy);
+            const float sx = __fadd_rn(__fadd_rn(tlx, t1), t2), sy = __fadd_rn(__fadd_rn(tly, t3), t4);
+            const float x0f = floorf(sx), y0f = floorf(sy);
+            const float ax = __fsub_rn(sx, x0f), ay = __fsub_rn(sy, y0f);
+            int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+            x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
+            y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+            const float bx = __fsub_rn(1.0f, ax), by = __fsub_rn(1.0f, ay);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float p00 = page[((size_t)y0 * W + x0) * 3 + c], p01 = page[((size_t)y0 * W + x1) * 3 + c];
+                const float p10 = page[((size_t)y1 * W + x0) * 3 + c], p11 = page[((size_t)y1 * W + x1) * 3 + c];
+                const float top = __fadd_rn(__fmul_rn(bx, p00), __fmul_rn(ax, p01)), bot = __fadd_rn(__fmul_rn(bx, p10), __fmul_rn(ax, p11));
+                float val = rintf(__fadd_rn(__fmul_rn(by, top), __fmul_rn(ay, bot)));
+                val = val < 0.f ? 0.f : (val > 255.f ? 255.f : val);
+                r3[c] = (uint8_t)val;
+            }
+        }
+        out[(size_t)t * 3 + 0] = r3[0]; out[(size_t)t * 3 + 1] = r3[1]; out[(size_t)t * 3 + 2] = r3[2];
+    }
+}
+
+inline int grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g > 256 * 32 ? 256 * 32 : (g ? g : 1));
+}
+
+}  // namespace
+
+size_t dbpost_workspace_bytes(int B, int Hp, int Wp, int maxc) {
+    const size_t per = (size_t)Hp * Wp;
+    const size_t seg_cap = (size_t)maxc * Hp;  // worst case: every candidate spans the page height
+    size_t n = 0;
+    n += per * B * 4 * 2;                       // label, cid
+    n += (size_t)B * Hp * 4 + 256;              // rowcnt
+    n += (size_t)B * 4 + 256;                   // ncomp
+    n += (size_t)B * maxc * 4 * 3 + 768;        // comp_root, ymin, ymax
+    n += (size_t)B * (maxc + 1) * 4 + 256;      // segoff
+    n += (size_t)B * seg_cap * 4 * 2 + 512;     // rowmin, rowmax
+    n += (size_t)B * seg_cap * 2 * 8 + 256;     // hull
+    n += (size_t)B * maxc * (8 * 4 + 4 + 4) + 768;
+    return n + 4096;
+}
+
+hipError_t dbpost_launch(const DbPostParams& p, void* workspace, hipStream_t st) {
+    const int B = p.B, Hp = p.Hp, Wp = p.Wp, maxc = p.max_boxes;
+    const size_t per = (size_t)Hp * Wp, seg_cap = (size_t)maxc * Hp;
+    uint8_t* w = static_cast<uint8_t*>(workspace);
+    auto take = [&](size_t bytes) { void* r = w; w += (bytes + 255) & ~(size_t)255; return r; };
+    int* label = static_cast<int*>(take(per * B * 4));
+    int* cid = static_cast<int*>(take(per * B * 4));
+    int* rowcnt = static_cast<int*>(take((size_t)B * Hp * 4));
+    int* ncomp = static_cast<int*>(take((size_t)B * 4));
+    int* comp_root = static_cast<int*>(take((size_t)B * maxc * 4));
+    int* ymin = static_cast<int*>(take((size_t)B * maxc * 4));
+    int* ymax = static_cast<int*>(take((size_t)B * maxc * 4));
+    int* segoff = static_cast<int*>(take((size_t)B * (maxc + 1) * 4));
+    int* rowmin = static_cast<int*>(take((size_t)B * seg_cap * 4));
+    int* rowmax = static_cast<int*>(take((size_t)B * seg_cap * 4));
+    int2* hull = static_cast<int2*>(take((size_t)B * seg_cap * 2 * 8));
+    int* box_tmp = static_cast<int*>(take((size_t)B * maxc * 8 * 4));
+    float* score_tmp = static_cast<float*>(take((size_t)B * maxc * 4));
+    int* valid_tmp = static_cast<int*>(take((size_t)B * maxc * 4));
+
+    const int gpix = grid_for(per * B);
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(B * Hp), dim3(64), 0, st, p.prob, label, Hp, Wp, p.valid_h, p.valid_w, p.thresh);
+    hipLaunchKernelGGL(ccl_merge_kernel, dim3(gpix), dim3(256), 0, st, label, B, Hp, Wp, p.valid_h, p.valid_w);
+    hipLaunchKernelGGL(ccl_compress_kernel, dim3(gpix), dim3(256), 0, st, label, B, Hp, Wp);
+    hipLaunchKernelGGL(root_count_kernel, dim3(B * Hp), dim3(64), 0, st, label, rowcnt, Hp, Wp);
+    hipLaunchKernelGGL(root_scan_kernel, dim3(B), dim3(64), 0, st, rowcnt, ncomp, Hp);
+    hipLaunchKernelGGL(root_assign_kernel, dim3(B * Hp), dim3(64), 0, st, label, rowcnt, cid, comp_root, ymin, ymax, Hp, Wp, maxc);
+    hipLaunchKernelGGL(comp_extent_kernel, dim3(gpix), dim3(256), 0, st, label, cid, ymin, ymax, B, Hp, Wp, maxc);
+    hipLaunchKernelGGL(seg_scan_kernel, dim3(B), dim3(64), 0, st, ncomp, ymin, ymax, segoff, maxc);
+    hipLaunchKernelGGL(seg_init_kernel, dim3(grid_for((size_t)B * seg_cap)), dim3(256), 0, st, rowmin, rowmax, (size_t)B * seg_cap);
+    hipLaunchKernelGGL(row_extremes_kernel, dim3(gpix), dim3(256), 0, st, label, cid, ymin, segoff, rowmin, rowmax, B, Hp, Wp, p.valid_w, maxc, seg_cap);
+    hipLaunchKernelGGL(comp_box_kernel, dim3(B * maxc), dim3(64), 0, st, p.prob, ncomp, ymin, ymax, segoff, rowmin, rowmax, hull, box_tmp,
+                       score_tmp, valid_tmp, Hp, Wp, p.valid_h, p.valid_w, maxc, seg_cap, p.box_thresh, p.unclip_ratio, p.min_size);
+    hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(64), 0, st, box_tmp, score_tmp, valid_tmp, p.boxes, p.scores, p.counts, maxc);
+    return hipGetLastError();
+}
+
+hipError_t rec_crop_launch(const uint8_t* pages, int H, int W, const int* quads, const int* page_idx, int n, uint8_t* crops, int* widths,
+                           hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rec_crop_kernel, dim3(n), dim3(256), 0, st, pages, H, W, quads, page_idx, crops, widths);
+    return hipGetLastError();
+}

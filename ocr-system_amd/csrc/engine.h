@@ -1,0 +1,78 @@
+// Host-side engine: weight loading/packing, workspace, and the det / rec layer schedules.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "conv_mfma.h"
+
+struct Tensor4 {
+    bf16_t* p = nullptr;
+    int n = 0, h = 0, w = 0, c = 0;
+    size_t elems() const { return (size_t)n * h * w * c; }
+};
+
+struct ConvLayer {
+    std::string name;
+    int ks = 1, stride = 1, cin = 0, cout = 0;  // padded gemm dims
+    int act = ACT_NONE;
+    bool convt = false;
+    int convt_c = 0;
+    ConvKernelCfg cfg{};
+    bf16_t* wpk = nullptr;  // device
+    float* bias = nullptr;  // device, n_tiles*BN
+};
+
+struct DwLayer { int k = 3, c = 0; bf16_t* w = nullptr; float* bias = nullptr; };
+struct SeLayer { int c = 0, mid = 0; bf16_t *w1 = nullptr, *w2 = nullptr; float *b1 = nullptr, *b2 = nullptr; };
+
+struct RecBlock {
+    int k, cin, exp, cout, se_mid, stride_h, act;
+    bool se, res;
+    ConvLayer expand, project;
+    DwLayer dw;
+    SeLayer sel;
+};
+
+struct HostBlobTensor { int dtype; std::vector<int> dims; const uint8_t* data; size_t nbytes; };
+
+struct lumina_ocr {
+    int device = 0;
+    std::string err;
+    // ---- det ----
+    bool det_loaded = false;
+    std::map<std::string, ConvLayer> det;
+    bf16_t* stem_wpk = nullptr; float* stem_bias = nullptr;
+    // ---- rec ----
+    bool rec_loaded = false;
+    int num_classes = 0, ctc_ntiles = 0;
+    bf16_t* rstem_wpk = nullptr; float* rstem_bias = nullptr;
+    std::vector<RecBlock> rblocks;
+    ConvLayer rconv2, xproj[2];
+    bf16_t* whh[2] = {nullptr, nullptr};
+    bf16_t* ctc_wpk = nullptr; float* ctc_bias = nullptr;
+    // ---- workspace ----
+    uint8_t* ws = nullptr; size_t ws_cap = 0, ws_off = 0;
+    std::vector<void*> owned;  // device allocations freed at destroy
+    int det_sub_batch = 4, rec_sub_batch = 2048;
+    std::map<std::string, Tensor4> taps;  // last forward's intermediates (debug / parity tests)
+    bool keep_taps = false;
+    // per-kernel event timing (bench roofline): accumulated conv-kernel time of the last det forward
+    bool time_convs = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_events;
+    std::vector<double> conv_flops;
+    std::vector<std::string> conv_names;
+};
+
+int locr_fail(lumina_ocr* eng, const char* what, const char* detail);
+bool parse_blob(lumina_ocr* eng, const void* blob, size_t n, std::map<std::string, HostBlobTensor>* out);
+
+int eng_load_det(lumina_ocr* eng, const void* blob, size_t n);
+int eng_load_rec(lumina_ocr* eng, const void* blob, size_t n);
+int eng_det_forward(lumina_ocr* eng, const uint8_t* pages, int B, int H, int W, int Hp, int Wp, bf16_t* prob, hipStream_t st);
+int eng_rec_forward(lumina_ocr* eng, const uint8_t* crops, const int* widths, int N, int* idx, float* prob, hipStream_t st);
+int eng_ws_reserve(lumina_ocr* eng, size_t bytes);
+void* eng_ws_alloc(lumina_ocr* eng, size_t bytes);
+int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4* y, const Tensor4* res, int res_shift, int out_mode,
+                 int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st);

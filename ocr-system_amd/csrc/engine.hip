@@ -1,0 +1,519 @@
+// Engine: LOCW weight-blob parsing + packing, device workspace, det (DBNet-R18vd) and rec
+// (CRNN-MobileNetV3) layer schedules.  Layer names/shapes mirror lumina_ocr/arch.py.
+#include "engine.h"
+
+#include <cstring>
+
+#include "ops.h"
+#include "stem_conv.h"
+
+int locr_fail(lumina_ocr* eng, const char* what, const char* detail) {
+    if (eng) eng->err = std::string(what) + ": " + (detail ? detail : "");
+    return 1;
+}
+
+#define HIPCHK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) return locr_fail(eng, #expr, hipGetErrorString(_e));    \
+    } while (0)
+
+// ------------------------------------------------------------------------------ blob
+bool parse_blob(lumina_ocr* eng, const void* blob, size_t n, std::map<std::string, HostBlobTensor>* out) {
+    const uint8_t* b = static_cast<const uint8_t*>(blob);
+    if (n < 12 || memcmp(b, "LOCW", 4) != 0) { locr_fail(eng, "parse_blob", "bad magic"); return false; }
+    uint32_t ver, cnt;
+    memcpy(&ver, b + 4, 4); memcpy(&cnt, b + 8, 4);
+    if (ver != 1) { locr_fail(eng, "parse_blob", "unsupported version"); return false; }
+    size_t off = 12;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        if (off + 2 > n) { locr_fail(eng, "parse_blob", "truncated"); return false; }
+        uint16_t ln; memcpy(&ln, b + off, 2); off += 2;
+        if (off + ln + 2 > n) { locr_fail(eng, "parse_blob", "truncated"); return false; }
+        std::string name(reinterpret_cast<const char*>(b + off), ln); off += ln;
+        HostBlobTensor t;
+        t.dtype = b[off]; const int nd = b[off + 1]; off += 2;
+        if (off + 4 * (size_t)nd + 8 > n) { locr_fail(eng, "parse_blob", "truncated"); return false; }
+        for (int d = 0; d < nd; ++d) { uint32_t v; memcpy(&v, b + off, 4); off += 4; t.dims.push_back((int)v); }
+        uint64_t nb; memcpy(&nb, b + off, 8); off += 8;
+        off += (16 - off % 16) % 16;
+        if (off + nb > n) { locr_fail(eng, "parse_blob", "truncated data"); return false; }
+        t.data = b + off; t.nbytes = (size_t)nb; off += nb;
+        (*out)[name] = t;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------ memory
+static void* dev_upload(lumina_ocr* eng, const void* host, size_t bytes) {
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    if (bytes && hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    eng->owned.push_back(d);
+    return d;
+}
+
+int eng_ws_reserve(lumina_ocr* eng, size_t bytes) {
+    if (bytes <= eng->ws_cap) return 0;
+    HIPCHK(hipDeviceSynchronize());
+    if (eng->ws) HIPCHK(hipFree(eng->ws));
+    eng->ws = nullptr; eng->ws_cap = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->ws), bytes));
+    eng->ws_cap = bytes;
+    return 0;
+}
+
+void* eng_ws_alloc(lumina_ocr* eng, size_t bytes) {
+    const size_t a = (eng->ws_off + 255) & ~(size_t)255;
+    eng->ws_off = a + bytes;
+    if (eng->ws == nullptr || eng->ws_off > eng->ws_cap) return nullptr;  // dry run or overflow
+    return eng->ws + a;
+}
+
+static Tensor4 ws_tensor(lumina_ocr* eng, int n, int h, int w, int c) {
+    Tensor4 t; t.n = n; t.h = h; t.w = w; t.c = c;
+    t.p = static_cast<bf16_t*>(eng_ws_alloc(eng, t.elems() * sizeof(bf16_t)));
+    return t;
+}
+
+static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------ layer construction
+static bool get_wb(lumina_ocr* eng, const std::map<std::string, HostBlobTensor>& m, const std::string& name,
+                   const HostBlobTensor** w, const HostBlobTensor** b) {
+    auto iw = m.find(name + ".w"), ib = m.find(name + ".b");
+    if (iw == m.end() || ib == m.end() || iw->second.dtype != 1 || ib->second.dtype != 0) {
+        locr_fail(eng, "missing/ill-typed tensor", name.c_str());
+        return false;
+    }
+    *w = &iw->second; *b = &ib->second;
+    return true;
+}
+
+// Build a conv layer from blob tensor name.w [cout_r][ks][ks][cin_r] (bf16) / name.b [cout_r or bias_r] (f32).
+static bool make_conv(lumina_ocr* eng, const std::map<std::string, HostBlobTensor>& m, const std::string& name, int ks, int stride,
+                      int cin_r, int cout_r, int cin_p, int cout_p, int act, ConvLayer* L, int bias_repeat = 1) {
+    const HostBlobTensor *w, *b;
+    if (!get_wb(eng, m, name, &w, &b)) return false;
+    if (w->dims.size() != 4 || w->dims[0] != cout_r || w->dims[1] != ks || w->dims[3] != cin_r ||
+        (int)b->dims[0] * bias_repeat != cout_r) {
+        locr_fail(eng, "unexpected tensor shape", name.c_str());
+        return false;
+    }
+    L->name = name; L->ks = ks; L->stride = stride; L->cin = cin_p; L->cout = cout_p; L->act = act;
+    if (!conv_pick_cfg(ks, stride, cin_p, cout_p, &L->cfg)) { locr_fail(eng, "no conv kernel config", name.c_str()); return false; }
+    const int taps = ks * ks;
+    std::vector<bf16_t> padded((size_t)cout_p * taps * cin_p, 0);
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(w->data);
+    for (int co = 0; co < cout_r; ++co)
+        for (int t = 0; t < taps; ++t)
+            memcpy(&padded[((size_t)co * taps + t) * cin_p], &src[((size_t)co * taps + t) * cin_r], sizeof(bf16_t) * cin_r);
+    std::vector<bf16_t> packed(conv_packed_weight_elems(cout_p, ks, cin_p, L->cfg.bn));
+    pack_conv_weights(padded.data(), cout_p, ks, cin_p, L->cfg.bn, L->cfg.ck, packed.data());
+    L->wpk = static_cast<bf16_t*>(dev_upload(eng, packed.data(), packed.size() * sizeof(bf16_t)));
+    const int ntiles = (cout_p + L->cfg.bn - 1) / L->cfg.bn;
+    std::vector<float> bias((size_t)ntiles * L->cfg.bn, 0.f);
+    const float* bs = reinterpret_cast<const float*>(b->data);
+    const int bn_r = b->dims[0];
+    for (int i = 0; i < cout_r; ++i) bias[i] = bs[i % bn_r];
+    L->bias = static_cast<float*>(dev_upload(eng, bias.data(), bias.size() * sizeof(float)));
+    if (!L->wpk || !L->bias) { locr_fail(eng, "device upload failed", name.c_str()); return false; }
+    return true;
+}
+
+int eng_load_det(lumina_ocr* eng, const void* blob, size_t n) {
+    std::map<std::string, HostBlobTensor> m;
+    if (!parse_blob(eng, blob, n, &m)) return 1;
+    HIPCHK(hipSetDevice(eng->device));
+    eng->det.clear();
+    // stem.conv1 (Cin = 3): dedicated kernel
+    {
+        const HostBlobTensor *w, *b;
+        if (!get_wb(eng, m, "stem.conv1", &w, &b)) return 1;
+        if (w->dims.size() != 4 || w->dims[0] != 32 || w->dims[1] != 3 || w->dims[3] != 3) return locr_fail(eng, "stem.conv1", "shape");
+        bf16_t packed[2 * 2 * 32 * 8];
+        pack_stem_weights(reinterpret_cast<const bf16_t*>(w->data), 32, packed);
+        eng->stem_wpk = static_cast<bf16_t*>(dev_upload(eng, packed, sizeof(packed)));
+        eng->stem_bias = static_cast<float*>(dev_upload(eng, b->data, 32 * sizeof(float)));
+    }
+    auto add = [&](const std::string& name, int ks, int stride, int cin, int cout, int act) -> bool {
+        return make_conv(eng, m, name, ks, stride, cin, cout, cin, cout, act, &eng->det[name]);
+    };
+    if (!add("stem.conv2", 3, 1, 32, 32, ACT_RELU) || !add("stem.conv3", 3, 1, 32, 64, ACT_RELU)) return 1;
+    const int chs[4] = {64, 128, 256, 512};
+    int cin = 64;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 2; ++j) {
+            const std::string p = "s" + std::to_string(i) + ".b" + std::to_string(j);
+            const int stride = (i > 0 && j == 0) ? 2 : 1;
+            if (!add(p + ".conv0", 3, stride, cin, chs[i], ACT_RELU)) return 1;
+            if (!add(p + ".conv1", 3, 1, chs[i], chs[i], ACT_RELU)) return 1;
+            if (j == 0) {
+                if (i == 0) { if (!add(p + ".short", 1, 1, cin, chs[i], ACT_NONE)) return 1; }
+                else { if (!add(p + ".short", 2, 2, cin, chs[i], ACT_NONE)) return 1; }
+            }
+            cin = chs[i];
+        }
+    }
+    for (int l = 5; l >= 2; --l) {
+        if (!add("fpn.in" + std::to_string(l), 1, 1, chs[l - 2], 256, ACT_NONE)) return 1;
+        if (!add("fpn.p" + std::to_string(l), 3, 1, 256, 64, ACT_NONE)) return 1;
+    }
+    if (!add("head.conv1", 3, 1, 256, 64, ACT_RELU)) return 1;
+    {
+        ConvLayer& L = eng->det["head.convt2"];
+        if (!make_conv(eng, m, "head.convt2", 1, 1, 64, 256, 64, 256, ACT_RELU, &L, 4)) return 1;
+        L.convt = true; L.convt_c = 64;
+        ConvLayer& L3 = eng->det["head.convt3"];
+        if (!make_conv(eng, m, "head.convt3", 1, 1, 64, 4, 64, 4, ACT_SIGMOID, &L3, 4)) return 1;
+        L3.convt = true; L3.convt_c = 1;
+    }
+    eng->det_loaded = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ conv dispatch
+int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4* y, const Tensor4* res, int res_shift, int out_mode,
+                 int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st) {
+    ConvParams p{};
+    p.x = x.p; p.wpk = L.wpk; p.bias = L.bias; p.res = res ? res->p : nullptr; p.y = y->p;
+    p.Cin = L.cin; p.Cout = L.cout; p.act = L.act;
+    p.out_mode = out_mode; p.up_shift = up_shift; p.convt_c = L.convt_c;
+    if (flat) {  // 1x1 conv == GEMM over all pixels: re-tile as rows of 32 so every 8x32 tile is full
+        const long long m = (long long)x.n * x.h * x.w;
+        p.N = 1; p.W = 32; p.H = (int)((m + 31) / 32); p.pix_limit = (int)m;
+        p.Ho = p.H; p.Wo = 32;
+        p.res_h = p.H; p.res_w = 32;
+    } else {
+        p.N = x.n; p.H = x.h; p.W = x.w; p.pix_limit = 0;
+        p.Ho = (L.ks == 3) ? (x.h - 1) / L.stride + 1 : x.h / L.stride;
+        p.Wo = (L.ks == 3) ? (x.w - 1) / L.stride + 1 : x.w / L.stride;
+        if (res) { p.res_h = res->h; p.res_w = res->w; }
+    }
+    p.res_shift = res_shift;
+    p.res_cstride = res ? res->c : 0;
+    p.y_cstride = y_cstride ? y_cstride : y->c;
+    p.y_coff = y_coff;
+    if (x.c != L.cin) return locr_fail(eng, "conv input channels mismatch", L.name.c_str());
+    if (x.p == nullptr || y->p == nullptr) return 0;  // dry run (workspace sizing)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (eng->time_convs) {
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, st));
+    }
+    hipError_t e = conv_launch(L.cfg, p, st);
+    if (e != hipSuccess) return locr_fail(eng, L.name.c_str(), hipGetErrorString(e));
+    if (eng->time_convs) {
+        HIPCHK(hipEventRecord(e1, st));
+        eng->conv_events.push_back({e0, e1});
+        const double px = flat ? (double)p.pix_limit : (double)p.N * p.Ho * p.Wo;
+        eng->conv_flops.push_back(2.0 * px * L.ks * L.ks * L.cin * L.cout);
+        eng->conv_names.push_back(L.name);
+    }
+    return 0;
+}
+
+#define RUN(expr) do { if ((expr) != 0) return 1; } while (0)
+
+static void tap(lumina_ocr* eng, const char* name, const Tensor4& t) { if (eng->keep_taps && t.p) eng->taps[name] = t; }
+
+// ------------------------------------------------------------------------------ det forward
+static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, int W, int Hp, int Wp, bf16_t* prob, hipStream_t st) {
+    eng->ws_off = 0;
+    const bool dry = (eng->ws == nullptr) || pages == nullptr;
+    auto& D = eng->det;
+    Tensor4 t1 = ws_tensor(eng, B, Hp / 2, Wp / 2, 32);
+    if (!dry && t1.p) {
+        StemParams sp{};
+        sp.x = pages; sp.wpk = eng->stem_wpk; sp.bias = eng->stem_bias; sp.y = t1.p; sp.valid_w_per_img = nullptr;
+        sp.N = B; sp.H = H; sp.W = W; sp.valid_h = H; sp.valid_w = W; sp.Ho = Hp / 2; sp.Wo = Wp / 2; sp.Cout_store = 32;
+        sp.act = ACT_RELU;
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+        for (int c = 0; c < 3; ++c) { sp.scale[c] = 1.0f / (255.0f * stdv[c]); sp.shift[c] = -mean[c] / stdv[c]; }
+        hipError_t e = stem_conv_launch(sp, st);
+        if (e != hipSuccess) return locr_fail(eng, "stem.conv1", hipGetErrorString(e));
+    }
+    tap(eng, "stem.conv1", t1);
+    Tensor4 t2 = ws_tensor(eng, B, Hp / 2, Wp / 2, 32);
+    RUN(eng_run_conv(eng, D["stem.conv2"], t1, &t2, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "stem.conv2", t2);
+    Tensor4 t3 = ws_tensor(eng, B, Hp / 2, Wp / 2, 64);
+    RUN(eng_run_conv(eng, D["stem.conv3"], t2, &t3, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "stem.conv3", t3);
+    Tensor4 x = ws_tensor(eng, B, Hp / 4, Wp / 4, 64);
+    if (!dry && x.p) {
+        hipError_t e = maxpool_launch(t3.p, x.p, B, t3.h, t3.w, 64, 3, 2, 1, x.h, x.w, st);
+        if (e != hipSuccess) return locr_fail(eng, "stem.pool", hipGetErrorString(e));
+    }
+    tap(eng, "stem.pool", x);
+    const int chs[4] = {64, 128, 256, 512};
+    Tensor4 feats[4];
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 2; ++j) {
+            const std::string p = "s" + std::to_string(i) + ".b" + std::to_string(j);
+            const int stride = (i > 0 && j == 0) ? 2 : 1;
+            Tensor4 y = ws_tensor(eng, B, x.h / stride, x.w / stride, chs[i]);
+            RUN(eng_run_conv(eng, D[p + ".conv0"], x, &y, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st));
+            Tensor4 sc = x;
+            if (j == 0) {
+                sc = ws_tensor(eng, B, y.h, y.w, chs[i]);
+                RUN(eng_run_conv(eng, D[p + ".short"], x, &sc, nullptr, 0, OUT_NORMAL, 0, 0, 0, i == 0, st));
+            }
+            Tensor4 o = ws_tensor(eng, B, y.h, y.w, chs[i]);
+            RUN(eng_run_conv(eng, D[p + ".conv1"], y, &o, &sc, 0, OUT_NORMAL, 0, 0, 0, false, st));
+            tap(eng, p.c_str(), o);
+            x = o;
+        }
+        feats[i] = x;
+    }
+    // FPN: laterals with fused top-down nearest-upsample add
+    Tensor4 in5 = ws_tensor(eng, B, feats[3].h, feats[3].w, 256);
+    RUN(eng_run_conv(eng, D["fpn.in5"], feats[3], &in5, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st));
+    Tensor4 out4 = ws_tensor(eng, B, feats[2].h, feats[2].w, 256);
+    RUN(eng_run_conv(eng, D["fpn.in4"], feats[2], &out4, &in5, 1, OUT_NORMAL, 0, 0, 0, false, st));
+    Tensor4 out3 = ws_tensor(eng, B, feats[1].h, feats[1].w, 256);
+    RUN(eng_run_conv(eng, D["fpn.in3"], feats[1], &out3, &out4, 1, OUT_NORMAL, 0, 0, 0, false, st));
+    Tensor4 out2 = ws_tensor(eng, B, feats[0].h, feats[0].w, 256);
+    RUN(eng_run_conv(eng, D["fpn.in2"], feats[0], &out2, &out3, 1, OUT_NORMAL, 0, 0, 0, false, st));
+    // smooth convs write straight into the channel slices of the 1/4-resolution concat (replicated)
+    Tensor4 fuse = ws_tensor(eng, B, Hp / 4, Wp / 4, 256);
+    RUN(eng_run_conv(eng, D["fpn.p5"], in5, &fuse, nullptr, 0, OUT_UPSAMPLE, 3, 256, 0, false, st));
+    RUN(eng_run_conv(eng, D["fpn.p4"], out4, &fuse, nullptr, 0, OUT_UPSAMPLE, 2, 256, 64, false, st));
+    RUN(eng_run_conv(eng, D["fpn.p3"], out3, &fuse, nullptr, 0, OUT_UPSAMPLE, 1, 256, 128, false, st));
+    RUN(eng_run_conv(eng, D["fpn.p2"], out2, &fuse, nullptr, 0, OUT_NORMAL, 0, 256, 192, false, st));
+    tap(eng, "fpn.fuse", fuse);
+    Tensor4 h1 = ws_tensor(eng, B, Hp / 4, Wp / 4, 64);
+    RUN(eng_run_conv(eng, D["head.conv1"], fuse, &h1, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "head.conv1", h1);
+    Tensor4 h2 = ws_tensor(eng, B, Hp / 2, Wp / 2, 64);
+    RUN(eng_run_conv(eng, D["head.convt2"], h1, &h2, nullptr, 0, OUT_CONVT, 0, 0, 0, false, st)); tap(eng, "head.convt2", h2);
+    Tensor4 pm; pm.p = prob; pm.n = B; pm.h = Hp; pm.w = Wp; pm.c = 1;
+    if (dry) pm.p = nullptr;
+    RUN(eng_run_conv(eng, D["head.convt3"], h2, &pm, nullptr, 0, OUT_CONVT1, 0, 1, 0, false, st));
+    return 0;
+}
+
+int eng_det_forward(lumina_ocr* eng, const uint8_t* pages, int B, int H, int W, int Hp, int Wp, bf16_t* prob, hipStream_t st) {
+    if (!eng->det_loaded) return locr_fail(eng, "det_forward", "det weights not loaded");
+    if (Hp % 32 || Wp % 32 || Hp < H || Wp < W || B <= 0) return locr_fail(eng, "det_forward", "Hp/Wp must be multiples of 32 and >= H/W");
+    HIPCHK(hipSetDevice(eng->device));
+    const int sb = eng->det_sub_batch < B ? eng->det_sub_batch : B;
+    // size the workspace with a dry run
+    uint8_t* keep = eng->ws; eng->ws = nullptr;
+    const bool kt = eng->keep_taps; eng->keep_taps = false;
+    int rc = det_forward_sub(eng, nullptr, sb, H, W, Hp, Wp, nullptr, st);
+    eng->keep_taps = kt;
+    const size_t need = eng->ws_off + 4096;
+    eng->ws = keep;
+    if (rc) return rc;
+    RUN(eng_ws_reserve(eng, need));
+    eng->taps.clear();
+    for (int b0 = 0; b0 < B; b0 += sb) {
+        const int nb = (B - b0) < sb ? (B - b0) : sb;
+        RUN(det_forward_sub(eng, pages + (size_t)b0 * H * W * 3, nb, H, W, Hp, Wp, prob + (size_t)b0 * Hp * Wp, st));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ rec
+static inline int cp16(int c) { return rup(c, 16); }
+static int make_div(double v, int d = 8) {
+    int nv = (int)(v + d / 2.0) / d * d;
+    if (nv < d) nv = d;
+    if (nv < 0.9 * v) nv += d;
+    return nv;
+}
+
+static bool make_dw(lumina_ocr* eng, const std::map<std::string, HostBlobTensor>& m, const std::string& name, int k, int c_r, int c_p, DwLayer* L) {
+    const HostBlobTensor *w, *b;
+    if (!get_wb(eng, m, name, &w, &b)) return false;
+    if (w->dims.size() != 4 || w->dims[0] != c_r || w->dims[1] != k || w->dims[3] != 1) { locr_fail(eng, "dw shape", name.c_str()); return false; }
+    std::vector<bf16_t> wt((size_t)k * k * c_p, 0);
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(w->data);
+    for (int c = 0; c < c_r; ++c)
+        for (int t = 0; t < k * k; ++t) wt[(size_t)t * c_p + c] = src[(size_t)c * k * k + t];
+    std::vector<float> bias(c_p, 0.f);
+    memcpy(bias.data(), b->data, sizeof(float) * c_r);
+    L->k = k; L->c = c_p;
+    L->w = static_cast<bf16_t*>(dev_upload(eng, wt.data(), wt.size() * sizeof(bf16_t)));
+    L->bias = static_cast<float*>(dev_upload(eng, bias.data(), bias.size() * sizeof(float)));
+    return L->w && L->bias;
+}
+
+static bool make_se(lumina_ocr* eng, const std::map<std::string, HostBlobTensor>& m, const std::string& pfx, int c_r, int c_p, int mid, SeLayer* L) {
+    const HostBlobTensor *w1, *b1, *w2, *b2;
+    if (!get_wb(eng, m, pfx + ".se1", &w1, &b1) || !get_wb(eng, m, pfx + ".se2", &w2, &b2)) return false;
+    if (w1->dims[0] != mid || w1->dims[3] != c_r || w2->dims[0] != c_r || w2->dims[3] != mid) { locr_fail(eng, "se shape", pfx.c_str()); return false; }
+    std::vector<bf16_t> a((size_t)mid * c_p, 0), bmat((size_t)c_p * mid, 0);
+    const bf16_t* s1 = reinterpret_cast<const bf16_t*>(w1->data);
+    const bf16_t* s2 = reinterpret_cast<const bf16_t*>(w2->data);
+    for (int i = 0; i < mid; ++i) memcpy(&a[(size_t)i * c_p], &s1[(size_t)i * c_r], sizeof(bf16_t) * c_r);
+    memcpy(bmat.data(), s2, sizeof(bf16_t) * (size_t)c_r * mid);
+    std::vector<float> bb2(c_p, 0.f);
+    memcpy(bb2.data(), b2->data, sizeof(float) * c_r);
+    L->c = c_p; L->mid = mid;
+    L->w1 = static_cast<bf16_t*>(dev_upload(eng, a.data(), a.size() * sizeof(bf16_t)));
+    L->w2 = static_cast<bf16_t*>(dev_upload(eng, bmat.data(), bmat.size() * sizeof(bf16_t)));
+    L->b1 = static_cast<float*>(dev_upload(eng, b1->data, sizeof(float) * mid));
+    L->b2 = static_cast<float*>(dev_upload(eng, bb2.data(), bb2.size() * sizeof(float)));
+    return L->w1 && L->w2 && L->b1 && L->b2;
+}
+
+int eng_load_rec(lumina_ocr* eng, const void* blob, size_t n) {
+    std::map<std::string, HostBlobTensor> m;
+    if (!parse_blob(eng, blob, n, &m)) return 1;
+    HIPCHK(hipSetDevice(eng->device));
+    const double scale = 0.5;
+    const int c0 = make_div(16 * scale);
+    {
+        const HostBlobTensor *w, *b;
+        if (!get_wb(eng, m, "rec.conv1", &w, &b)) return 1;
+        if (w->dims[0] != c0 || w->dims[1] != 3 || w->dims[3] != 3) return locr_fail(eng, "rec.conv1", "shape");
+        bf16_t packed[2 * 2 * 32 * 8];
+        pack_stem_weights(reinterpret_cast<const bf16_t*>(w->data), c0, packed);
+        float bias[32] = {0};
+        memcpy(bias, b->data, sizeof(float) * c0);
+        eng->rstem_wpk = static_cast<bf16_t*>(dev_upload(eng, packed, sizeof(packed)));
+        eng->rstem_bias = static_cast<float*>(dev_upload(eng, bias, sizeof(bias)));
+    }
+    struct Row { int k, exp, c; bool se; int act, sh; };
+    const Row rows[11] = {{3, 16, 16, true, ACT_RELU, 1},    {3, 72, 24, false, ACT_RELU, 2},   {3, 88, 24, false, ACT_RELU, 1},
+                          {5, 96, 40, true, ACT_HSWISH, 2},  {5, 240, 40, true, ACT_HSWISH, 1}, {5, 240, 40, true, ACT_HSWISH, 1},
+                          {5, 120, 48, true, ACT_HSWISH, 1}, {5, 144, 48, true, ACT_HSWISH, 1}, {5, 288, 96, true, ACT_HSWISH, 2},
+                          {5, 576, 96, true, ACT_HSWISH, 1}, {5, 576, 96, true, ACT_HSWISH, 1}};
+    eng->rblocks.clear();
+    eng->rblocks.resize(11);
+    int cin = c0;
+    for (int i = 0; i < 11; ++i) {
+        RecBlock& B = eng->rblocks[i];
+        B.k = rows[i].k; B.cin = cin; B.exp = make_div(rows[i].exp * scale); B.cout = make_div(rows[i].c * scale);
+        B.se = rows[i].se; B.se_mid = B.exp / 4; B.stride_h = rows[i].sh; B.act = rows[i].act;
+        B.res = (B.stride_h == 1 && B.cin == B.cout);
+        const std::string p = "rec.b" + std::to_string(i);
+        if (!make_conv(eng, m, p + ".expand", 1, 1, B.cin, B.exp, cp16(B.cin), cp16(B.exp), B.act, &B.expand)) return 1;
+        if (!make_dw(eng, m, p + ".dw", B.k, B.exp, cp16(B.exp), &B.dw)) return locr_fail(eng, "dw", p.c_str());
+        if (B.se && !make_se(eng, m, p, B.exp, cp16(B.exp), B.se_mid, &B.sel)) return 1;
+        if (!make_conv(eng, m, p + ".project", 1, 1, B.exp, B.cout, cp16(B.exp), cp16(B.cout), ACT_NONE, &B.project)) return 1;
+        cin = B.cout;
+    }
+    if (!make_conv(eng, m, "rec.conv2", 1, 1, cin, 288, cp16(cin), 288, ACT_HSWISH, &eng->rconv2)) return 1;
+    // LSTM: x-projection of both directions as one GEMM; recurrent weights [2][4H][H]
+    const int Hh = 96;
+    for (int l = 0; l < 2; ++l) {
+        const int din = l == 0 ? 288 : 2 * Hh;
+        const std::string pf = "lstm.l" + std::to_string(l) + ".fw", pb = "lstm.l" + std::to_string(l) + ".bw";
+        auto wf = m.find(pf + ".w_ih"), wb = m.find(pb + ".w_ih"), bf = m.find(pf + ".b"), bb = m.find(pb + ".b");
+        auto hf = m.find(pf + ".w_hh"), hb = m.find(pb + ".w_hh");
+        if (wf == m.end() || wb == m.end() || bf == m.end() || bb == m.end() || hf == m.end() || hb == m.end())
+            return locr_fail(eng, "lstm tensors missing", pf.c_str());
+        if (wf->second.dims[0] != 4 * Hh || wf->second.dims[1] != din || hf->second.dims[1] != Hh) return locr_fail(eng, "lstm shape", pf.c_str());
+        // synthesise a 1x1 conv blob entry [8H][1][1][din]
+        std::vector<uint8_t> wcat(wf->second.nbytes + wb->second.nbytes), bcat(bf->second.nbytes + bb->second.nbytes);
+        memcpy(wcat.data(), wf->second.data, wf->second.nbytes); memcpy(wcat.data() + wf->second.nbytes, wb->second.data, wb->second.nbytes);
+        memcpy(bcat.data(), bf->second.data, bf->second.nbytes); memcpy(bcat.data() + bf->second.nbytes, bb->second.data, bb->second.nbytes);
+        std::map<std::string, HostBlobTensor> mm;
+        mm["x.w"] = HostBlobTensor{1, {8 * Hh, 1, 1, din}, wcat.data(), wcat.size()};
+        mm["x.b"] = HostBlobTensor{0, {8 * Hh}, bcat.data(), bcat.size()};
+        if (!make_conv(eng, mm, "x", 1, 1, din, 8 * Hh, din, 8 * Hh, ACT_NONE, &eng->xproj[l])) return 1;
+        eng->xproj[l].name = "lstm.l" + std::to_string(l) + ".xproj";
+        std::vector<uint8_t> hcat(hf->second.nbytes + hb->second.nbytes);
+        memcpy(hcat.data(), hf->second.data, hf->second.nbytes); memcpy(hcat.data() + hf->second.nbytes, hb->second.data, hb->second.nbytes);
+        eng->whh[l] = static_cast<bf16_t*>(dev_upload(eng, hcat.data(), hcat.size()));
+        if (!eng->whh[l]) return locr_fail(eng, "upload", "whh");
+    }
+    {
+        auto w = m.find("ctc.fc.w"), b = m.find("ctc.fc.b");
+        if (w == m.end() || b == m.end() || w->second.dims[1] != 2 * Hh) return locr_fail(eng, "ctc.fc", "missing/shape");
+        const int C = w->second.dims[0];
+        eng->num_classes = C; eng->ctc_ntiles = (C + 127) / 128;
+        std::vector<bf16_t> packed(ctc_packed_weight_elems(C, 2 * Hh));
+        pack_ctc_weights(reinterpret_cast<const bf16_t*>(w->second.data), C, 2 * Hh, packed.data());
+        std::vector<float> bias((size_t)eng->ctc_ntiles * 128, -1.0e30f);
+        memcpy(bias.data(), b->second.data, sizeof(float) * C);
+        eng->ctc_wpk = static_cast<bf16_t*>(dev_upload(eng, packed.data(), packed.size() * sizeof(bf16_t)));
+        eng->ctc_bias = static_cast<float*>(dev_upload(eng, bias.data(), bias.size() * sizeof(float)));
+        if (!eng->ctc_wpk || !eng->ctc_bias) return locr_fail(eng, "upload", "ctc");
+    }
+    eng->rec_loaded = true;
+    return 0;
+}
+
+#define LAUNCH(name, expr)                                                                  \
+    do {                                                                                    \
+        if (!dry) { hipError_t _e = (expr); if (_e != hipSuccess) return locr_fail(eng, name, hipGetErrorString(_e)); } \
+    } while (0)
+
+static int rec_forward_sub(lumina_ocr* eng, const uint8_t* crops, const int* widths, int N, int* idx, float* prob, hipStream_t st) {
+    eng->ws_off = 0;
+    const bool dry = (eng->ws == nullptr) || crops == nullptr;
+    const int T = 80;
+    Tensor4 x = ws_tensor(eng, N, 16, 160, 16);
+    if (!dry && x.p) {
+        StemParams sp{};
+        sp.x = crops; sp.wpk = eng->rstem_wpk; sp.bias = eng->rstem_bias; sp.y = x.p; sp.valid_w_per_img = widths;
+        sp.N = N; sp.H = 32; sp.W = 320; sp.valid_h = 32; sp.valid_w = 320; sp.Ho = 16; sp.Wo = 160; sp.Cout_store = 16;
+        sp.act = ACT_HSWISH;
+        for (int c = 0; c < 3; ++c) { sp.scale[c] = 2.0f / 255.0f; sp.shift[c] = -1.0f; }
+        hipError_t e = stem_conv_launch(sp, st);
+        if (e != hipSuccess) return locr_fail(eng, "rec.conv1", hipGetErrorString(e));
+    }
+    tap(eng, "rec.conv1", x);
+    for (size_t bi = 0; bi < eng->rblocks.size(); ++bi) {
+        RecBlock& B = eng->rblocks[bi];
+        Tensor4 e1 = ws_tensor(eng, N, x.h, x.w, cp16(B.exp));
+        RUN(eng_run_conv(eng, B.expand, x, &e1, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
+        const int ho = (x.h + 2 * (B.k / 2) - B.k) / B.stride_h + 1;
+        Tensor4 d = ws_tensor(eng, N, ho, x.w, cp16(B.exp));
+        LAUNCH("dwconv", dwconv_launch(e1.p, B.dw.w, B.dw.bias, d.p, N, e1.h, e1.w, e1.c, B.k, B.stride_h, B.act, st));
+        if (B.se) {
+            bf16_t* gate = static_cast<bf16_t*>(eng_ws_alloc(eng, (size_t)N * d.c * sizeof(bf16_t)));
+            Tensor4 s = ws_tensor(eng, N, d.h, d.w, d.c);
+            LAUNCH("se_gate", se_gate_launch(d.p, B.sel.w1, B.sel.b1, B.sel.w2, B.sel.b2, gate, N, d.h * d.w, d.c, B.sel.mid, st));
+            LAUNCH("se_scale", se_scale_launch(d.p, gate, s.p, N, d.h * d.w, d.c, st));
+            d = s;
+        }
+        Tensor4 o = ws_tensor(eng, N, d.h, d.w, cp16(B.cout));
+        RUN(eng_run_conv(eng, B.project, d, &o, B.res ? &x : nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
+        tap(eng, ("rec.b" + std::to_string(bi)).c_str(), o);
+        x = o;
+    }
+    Tensor4 f = ws_tensor(eng, N, x.h, x.w, 288);
+    RUN(eng_run_conv(eng, eng->rconv2, x, &f, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st)); tap(eng, "rec.conv2", f);
+    Tensor4 seq = ws_tensor(eng, N, 1, T, 288);
+    LAUNCH("rec.pool", maxpool_launch(f.p, seq.p, N, f.h, f.w, 288, 2, 2, 0, 1, T, st));
+    tap(eng, "rec.feat", seq);
+    for (int l = 0; l < 2; ++l) {
+        Tensor4 xp = ws_tensor(eng, N, 1, T, 8 * 96);
+        RUN(eng_run_conv(eng, eng->xproj[l], seq, &xp, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
+        Tensor4 hs = ws_tensor(eng, N, 1, T, 2 * 96);
+        LAUNCH("lstm", lstm_recurrent_launch(xp.p, eng->whh[l], hs.p, N, T, st));
+        tap(eng, l == 0 ? "lstm.l0" : "lstm.l1", hs);
+        seq = hs;
+    }
+    if (!dry) {
+        CtcFcParams cp{};
+        cp.seq = seq.p; cp.wpk = eng->ctc_wpk; cp.bias = eng->ctc_bias; cp.out_idx = idx; cp.out_prob = prob;
+        cp.M = N * T; cp.K = 192; cp.C = eng->num_classes; cp.ntiles = eng->ctc_ntiles;
+        hipError_t e = ctc_fc_argmax_launch(cp, st);
+        if (e != hipSuccess) return locr_fail(eng, "ctc_fc_argmax", hipGetErrorString(e));
+    }
+    return 0;
+}
+
+int eng_rec_forward(lumina_ocr* eng, const uint8_t* crops, const int* widths, int N, int* idx, float* prob, hipStream_t st) {
+    if (!eng->rec_loaded) return locr_fail(eng, "rec_forward", "rec weights not loaded");
+    if (N <= 0) return 0;
+    HIPCHK(hipSetDevice(eng->device));
+    const int sb = eng->rec_sub_batch < N ? eng->rec_sub_batch : N;
+    uint8_t* keep = eng->ws; eng->ws = nullptr;
+    const bool kt = eng->keep_taps; eng->keep_taps = false;
+    int rc = rec_forward_sub(eng, nullptr, nullptr, sb, nullptr, nullptr, st);
+    eng->keep_taps = kt;
+    const size_t need = eng->ws_off + 4096;
+    eng->ws = keep;
+    if (rc) return rc;
+    RUN(eng_ws_reserve(eng, need));
+    eng->taps.clear();
+    for (int b0 = 0; b0 < N; b0 += sb) {
+        const int nb = (N - b0) < sb ? (N - b0) : sb;
+        RUN(rec_forward_sub(eng, crops + (size_t)b0 * 32 * 320 * 3, widths ? widths + b0 : nullptr, nb, idx + (size_t)b0 * 80, prob + (size_t)b0 * 80, st));
+    }
+    return 0;
+}

@@ -1,0 +1,385 @@
+// Bandwidth-bound helper kernels (NHWC bf16), the LSTM recurrence and the CTC tail for gfx950.
+// No reference counterpart exists; semantics are defined by oracle/nets.py.
+#include "ops.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4 v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xFFFF0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xFFFF0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xFFFF0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    return v;
+}
+
+// ------------------------------------------------------------------ max pool
+__global__ void maxpool_kernel(const bf16_t* x, bf16_t* y, int N, int H, int W, int C, int k, int s, int pad, int Ho, int Wo) {
+    const int cg = C >> 3;
+    const size_t total = (size_t)N * Ho * Wo * cg;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cg);
+        size_t t = i / cg;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -3.0e38f;
+        for (int dy = 0; dy < k; ++dy) {
+            const int iy = oy * s - pad + dy;
+            if (iy < 0 || iy >= H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int ix = ox * s - pad + dx;
+                if (ix < 0 || ix >= W) continue;
+                float f[8];
+                unpack8(*reinterpret_cast<const uint4*>(x + (((size_t)n * H + iy) * W + ix) * C + c8 * 8), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], f[j]);
+            }
+        }
+        *reinterpret_cast<uint4*>(y + i * 8) = pack8(m);
+    }
+}
+
+// ------------------------------------------------------------------ depthwise conv
+__global__ void dwconv_kernel(const bf16_t* x, const bf16_t* w, const float* bias, bf16_t* y, int N, int H, int W, int C,
+                              int k, int sh, int Ho, int act) {
+    const int cg = C >> 3, pad = k >> 1;
+    const size_t total = (size_t)N * Ho * W * cg;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cg);
+        size_t t = i / cg;
+        const int ox = (int)(t % W); t /= W;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = 0.f;
+        for (int dy = 0; dy < k; ++dy) {
+            const int iy = oy * sh - pad + dy;
+            if (iy < 0 || iy >= H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int ix = ox - pad + dx;
+                if (ix < 0 || ix >= W) continue;
+                float f[8], g[8];
+                unpack8(*reinterpret_cast<const uint4*>(x + (((size_t)n * H + iy) * W + ix) * C + c8 * 8), f);
+                unpack8(*reinterpret_cast<const uint4*>(w + (size_t)(dy * k + dx) * C + c8 * 8), g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = a[j] + f[j] * g[j];
+            }
+        }
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + c8 * 8), b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
+        a[0] += b0.x; a[1] += b0.y; a[2] += b0.z; a[3] += b0.w; a[4] += b1.x; a[5] += b1.y; a[6] += b1.z; a[7] += b1.w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = apply_act(a[j], act);
+        *reinterpret_cast<uint4*>(y + i * 8) = pack8(a);
+    }
+}
+
+// ------------------------------------------------------------------ squeeze-excite gate (one block per image)
+__global__ __launch_bounds__(256) void se_gate_kernel(const bf16_t* x, const bf16_t* w1, const float* b1, const bf16_t* w2,
+                                                      const float* b2, bf16_t* gate, int HW, int C, int mid) {
+    extern __shared__ float sm[];  // [256/cg][C] partial sums, then mean[C], hid[mid]
+    const int n = blockIdx.x, tid = threadIdx.x, cg = C >> 3;
+    const int groups = 256 / cg;  // pixel groups
+    const int c8 = tid % cg, pg = tid / cg;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    if (pg < groups) {
+        for (int px = pg; px < HW; px += groups) {
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + ((size_t)n * HW + px) * C + c8 * 8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += f[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sm[pg * C + c8 * 8 + j] = a[j];
+    }
+    __syncthreads();
+    float* mean = sm + groups * C;
+    float* hid = mean + C;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int g = 0; g < groups; ++g) s += sm[g * C + c];
+        mean[c] = bf16_to_f32(f32_to_bf16(s / (float)HW));
+    }
+    __syncthreads();
+    for (int m = tid; m < mid; m += 256) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s = s + bf16_to_f32(w1[(size_t)m * C + c]) * mean[c];
+        hid[m] = bf16_to_f32(f32_to_bf16(fmaxf(s + b1[m], 0.f)));
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int m = 0; m < mid; ++m) s = s + bf16_to_f32(w2[(size_t)c * mid + m]) * hid[m];
+        gate[(size_t)n * C + c] = f32_to_bf16(apply_act(s + b2[c], ACT_HSIGMOID));
+    }
+}
+
+__global__ void se_scale_kernel(const bf16_t* x, const bf16_t* gate, bf16_t* y, int N, int HW, int C) {
+    const int cg = C >> 3;
+    const size_t total = (size_t)N * HW * cg;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cg);
+        const int n = (int)(i / ((size_t)HW * cg));
+        float f[8], g[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + i * 8), f);
+        unpack8(*reinterpret_cast<const uint4*>(gate + (size_t)n * C + c8 * 8), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = f[j] * g[j];
+        *reinterpret_cast<uint4*>(y + i * 8) = pack8(f);
+    }
+}
+
+// ------------------------------------------------------------------ LSTM recurrence
+// One block = one (sequence, direction); 384 threads = 4 gates x 96 hidden rows; W_hh row in registers.
+constexpr int LH = 96;
+__global__ __launch_bounds__(384) void lstm_kernel(const bf16_t* xproj, const bf16_t* whh, bf16_t* out, int T) {
+    __shared__ float hs[LH];
+    __shared__ float gs[4 * LH];
+    const int n = blockIdx.x >> 1, dir = blockIdx.x & 1, tid = threadIdx.x;
+    float wr[LH];
+    const bf16_t* wrow = whh + ((size_t)dir * 4 * LH + tid) * LH;
+#pragma unroll
+    for (int k = 0; k < LH; k += 8) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(wrow + k), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wr[k + j] = f[j];
+    }
+    if (tid < LH) hs[tid] = 0.f;
+    float c = 0.f;
+    __syncthreads();
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        float pre = bf16_to_f32(xproj[((size_t)n * T + t) * (8 * LH) + dir * 4 * LH + tid]);
+#pragma unroll
+        for (int k = 0; k < LH; ++k) pre = pre + wr[k] * hs[k];
+        gs[tid] = pre;
+        __syncthreads();
+        if (tid < LH) {
+            const float ig = 1.f / (1.f + expf(-gs[tid])), fg = 1.f / (1.f + expf(-gs[LH + tid]));
+            const float gg = tanhf(gs[2 * LH + tid]), og = 1.f / (1.f + expf(-gs[3 * LH + tid]));
+            c = fg * c + ig * gg;
+            const bf16_t hb = f32_to_bf16(og * tanhf(c));
+            hs[tid] = bf16_to_f32(hb);
+            out[((size_t)n * T + t) * (2 * LH) + dir * LH + tid] = hb;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ CTC head: fused FC + argmax + softmax-max
+// A-stationary MFMA GEMM: the block keeps its 256 sequence rows (K <= 192) in LDS and streams all
+// 128-class weight tiles through a second LDS region; running (max, argmax, sum-exp) stay in registers,
+// the [M, C] logits never exist in memory.
+constexpr int CT_ROWS = 256, CT_BN = 128, CT_KMAX = 192;
+constexpr int CT_PLANE_A = CT_ROWS + 4;  // entries, == 4 (mod 16)
+
+__global__ __launch_bounds__(256, 1) void ctc_fc_argmax_kernel(const CtcFcParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int npl = p.K >> 3;
+    unsigned char* sA = smem;
+    unsigned char* sW = smem + (size_t)npl * CT_PLANE_A * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * CT_ROWS;
+
+    for (int i = tid; i < CT_ROWS * npl; i += 256) {
+        const int row = i / npl, c = i - row * npl;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row0 + row < p.M) v = *reinterpret_cast<const uint4*>(p.seq + (size_t)(row0 + row) * p.K + c * 8);
+        *reinterpret_cast<uint4*>(sA + ((size_t)c * CT_PLANE_A + row) * 16) = v;
+    }
+    const int w_items = CT_BN * npl;           // 16-byte items per weight tile (<= 3072)
+    const int wit = (w_items + 255) / 256;     // <= 12
+    uint4 wreg[12];
+#define CTC_LOAD_W(tile_)                                                                              \
+    {                                                                                                  \
+        const uint4* src = reinterpret_cast<const uint4*>(p.wpk + (size_t)(tile_) * w_items * 8);      \
+        _Pragma("unroll") for (int it = 0; it < 12; ++it) {                                            \
+            const int i = tid + 256 * it;                                                              \
+            uint4 t_ = make_uint4(0, 0, 0, 0);                                                         \
+            if (it < wit && i < w_items) t_ = src[i];                                                  \
+            wreg[it] = t_;                                                                             \
+        }                                                                                              \
+    }
+    float run_m[2], run_s[2];
+    int run_i[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { run_m[mt] = -3.0e38f; run_s[mt] = 0.f; run_i[mt] = 0; }
+
+    CTC_LOAD_W(0);
+    const int ksteps = p.K >> 4;
+    for (int tile = 0; tile < p.ntiles; ++tile) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const int i = tid + 256 * it;
+            if (it < wit && i < w_items) *reinterpret_cast<uint4*>(sW + (size_t)i * 16) = wreg[it];
+        }
+        __syncthreads();
+        if (tile + 1 < p.ntiles) CTC_LOAD_W(tile + 1);
+        f32x16_t acc[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+        for (int kc = 0; kc < ksteps; ++kc) {
+            bf16x8_t bfr[2], afr[4];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                bfr[mt] = *reinterpret_cast<const bf16x8_t*>(sA + ((size_t)(2 * kc + h) * CT_PLANE_A + wave * 64 + mt * 32 + r) * 16);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                afr[nt] = *reinterpret_cast<const bf16x8_t*>(sW + ((size_t)(2 * kc + h) * CT_BN + nt * 32 + r) * 16);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[nt], bfr[mt], acc[mt][nt], 0, 0, 0);
+        }
+        // per-tile reduction over this lane's 64 classes, then the partner half-wave, then the running state
+        const float* bt = p.bias + tile * CT_BN;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float tm = -3.0e38f;
+            int ti = 0;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int cls = nt * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    const float v = acc[mt][nt][j] + bt[cls];
+                    acc[mt][nt][j] = v;
+                    if (v > tm) { tm = v; ti = cls; }
+                }
+            const float om = __shfl_xor(tm, 32);
+            const int oi = __shfl_xor(ti, 32);
+            if (om > tm || (om == tm && oi < ti)) { tm = om; ti = oi; }
+            float ts = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ts += expf(acc[mt][nt][j] - tm);
+            ts += __shfl_xor(ts, 32);
+            if (tm > run_m[mt]) {
+                run_s[mt] = run_s[mt] * expf(run_m[mt] - tm) + ts;
+                run_m[mt] = tm;
+                run_i[mt] = tile * CT_BN + ti;
+            } else {
+                run_s[mt] += ts * expf(tm - run_m[mt]);
+            }
+        }
+    }
+    if (h == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int row = row0 + wave * 64 + mt * 32 + r;
+            if (row < p.M) { p.out_idx[row] = run_i[mt]; p.out_prob[row] = 1.f / run_s[mt]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ CTC greedy collapse (one wave per sequence)
+__global__ __launch_bounds__(64) void ctc_collapse_kernel(const int* idx, const float* prob, int* text, int* len, float* score, int T) {
+    __shared__ float kept_p[128];
+    const int n = blockIdx.x, lane = threadIdx.x;
+    int base = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const int cur = t < T ? idx[(size_t)n * T + t] : 0;
+        int prev = __shfl_up(cur, 1);
+        if (lane == 0) prev = t0 > 0 ? idx[(size_t)n * T + t0 - 1] : -1;
+        const bool keep = t < T && cur != 0 && cur != prev;
+        const unsigned long long mask = __ballot(keep);
+        const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep) { text[(size_t)n * T + pos] = cur; kept_p[pos] = prob[(size_t)n * T + t]; }
+        base += __popcll(mask);
+    }
+    for (int t = base + lane; t < T; t += 64) text[(size_t)n * T + t] = -1;
+    __syncthreads();
+    if (lane == 0) {
+        float s = 0.f;
+        for (int k = 0; k < base; ++k) s = s + kept_p[k];  // time order, fp32 (oracle/nets.py ctc_greedy)
+        len[n] = base;
+        score[n] = base ? s / (float)base : 0.f;
+    }
+}
+
+int grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g > 256 * 32 ? 256 * 32 : (g ? g : 1));
+}
+
+}  // namespace
+
+hipError_t maxpool_launch(const bf16_t* x, bf16_t* y, int N, int H, int W, int C, int k, int s, int pad, int Ho, int Wo, hipStream_t st) {
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(256), 0, st, x, y, N, H, W, C, k, s, pad, Ho, Wo);
+    return hipGetLastError();
+}
+
+hipError_t dwconv_launch(const bf16_t* x, const bf16_t* w, const float* bias, bf16_t* y, int N, int H, int W, int C, int k,
+                         int sh, int act, hipStream_t st) {
+    const int Ho = (H + 2 * (k / 2) - k) / sh + 1;
+    hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for((size_t)N * Ho * W * (C / 8))), dim3(256), 0, st, x, w, bias, y, N, H, W, C, k, sh, Ho, act);
+    return hipGetLastError();
+}
+
+hipError_t se_gate_launch(const bf16_t* x, const bf16_t* w1, const float* b1, const bf16_t* w2, const float* b2, bf16_t* gate,
+                          int N, int HW, int C, int mid, hipStream_t st) {
+    const int cg = C / 8, groups = 256 / cg;
+    const size_t lds = ((size_t)groups * C + C + mid) * sizeof(float);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), lds, st, x, w1, b1, w2, b2, gate, HW, C, mid);
+    return hipGetLastError();
+}
+
+hipError_t se_scale_launch(const bf16_t* x, const bf16_t* gate, bf16_t* y, int N, int HW, int C, hipStream_t st) {
+    hipLaunchKernelGGL(se_scale_kernel, dim3(grid_for((size_t)N * HW * (C / 8))), dim3(256), 0, st, x, gate, y, N, HW, C);
+    return hipGetLastError();
+}
+
+hipError_t lstm_recurrent_launch(const bf16_t* xproj, const bf16_t* whh, bf16_t* out, int N, int T, hipStream_t st) {
+    hipLaunchKernelGGL(lstm_kernel, dim3(N * 2), dim3(384), 0, st, xproj, whh, out, T);
+    return hipGetLastError();
+}
+
+size_t ctc_packed_weight_elems(int C, int K) { return (size_t)((C + CT_BN - 1) / CT_BN) * CT_BN * K; }
+
+void pack_ctc_weights(const bf16_t* w, int C, int K, bf16_t* out) {
+    const int ntiles = (C + CT_BN - 1) / CT_BN, npl = K / 8;
+    for (int t = 0; t < ntiles; ++t)
+        for (int c = 0; c < npl; ++c)
+            for (int n = 0; n < CT_BN; ++n)
+                for (int j = 0; j < 8; ++j) {
+                    const int cls = t * CT_BN + n;
+                    out[(((size_t)t * npl + c) * CT_BN + n) * 8 + j] = cls < C ? w[(size_t)cls * K + c * 8 + j] : (bf16_t)0;
+                }
+}
+
+hipError_t ctc_fc_argmax_launch(const CtcFcParams& p, hipStream_t st) {
+    if (p.K % 16 != 0 || p.K > CT_KMAX) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(p.K / 8) * (CT_PLANE_A + CT_BN) * 16;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_fc_argmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(ctc_fc_argmax_kernel, dim3((p.M + CT_ROWS - 1) / CT_ROWS), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t ctc_collapse_launch(const int* idx, const float* prob, int* text, int* len, float* score, int N, int T, hipStream_t st) {
+    if (T > 128) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(N), dim3(64), 0, st, idx, prob, text, len, score, T);
+    return hipGetLastError();
+}

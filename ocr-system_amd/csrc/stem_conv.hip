@@ -1,0 +1,157 @@
+// Stem convolution fused with input normalisation: u8 HWC page/crop -> 3x3 / stride 2 conv (Cin = 3)
+// -> bias + activation -> bf16 NHWC.  Also a standalone normalise kernel (u8 HWC -> bf16 NHWC/NCHW).
+//
+// The reference has no normalise-to-tensor step (its pre-processing stops at PIL images:
+// /root/reference/backend/utils/image_preprocessing.py:191-242); the definition
+//   xn = bf16( float(u8) * scale_c + shift_c ),  0 outside the valid page
+// is the build's (oracle/nets.py det_normalize / rec_normalize).
+//
+// One workgroup = 8 x 32 output pixels.  The (17 x 65) x 3 input halo is normalised once into
+// LDS as bf16; K = 27 (padded to 32) is two 32x32x16 MFMA steps whose B fragments are gathered
+// from LDS (for a fixed kh the 9 (kw, c) values of a pixel are contiguous), weights (A operand,
+// 2 KB, pre-packed [kstep][half][cout][8]) come straight from L2.
+#include "stem_conv.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32;
+constexpr int HH = 2 * (TH - 1) + 3, HW = 2 * (TW - 1) + 3;  // 17 x 65
+constexpr int ROW = HW * 3 + 1;                              // bf16 elements per halo row (odd -> fewer conflicts)
+constexpr int STAGE_PITCH = 32 * 2 + 16;
+
+__global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[256 * STAGE_PITCH > HH * ROW * 2 ? 256 * STAGE_PITCH : HH * ROW * 2];
+    bf16_t* halo = reinterpret_cast<bf16_t*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int bid = blockIdx.x;
+    const int n_img = bid / (tiles_x * tiles_y);
+    const int trem = bid - n_img * tiles_x * tiles_y;
+    const int tile_y = trem / tiles_x, tile_x = trem - tile_y * tiles_x;
+    const int vw = p.valid_w_per_img ? p.valid_w_per_img[n_img] : p.valid_w;
+    const int vh = p.valid_h;
+    const uint8_t* img = p.x + (size_t)n_img * p.H * p.W * 3;
+
+    // ---- stage + normalise the halo ----
+    const int iy0 = tile_y * TH * 2 - 1, ix0 = tile_x * TW * 2 - 1;
+    for (int i = tid; i < HH * HW * 3; i += 256) {
+        const int hy = i / (HW * 3), rem = i - hy * HW * 3;
+        const int hx = rem / 3, c = rem - hx * 3;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        float v = 0.f;
+        if (iy >= 0 && iy < vh && ix >= 0 && ix < vw) {
+            const float u = (float)img[((size_t)iy * p.W + ix) * 3 + c];
+            v = u * p.scale[c];
+            v = v + p.shift[c];
+        }
+        halo[hy * ROW + rem] = f32_to_bf16(v);
+    }
+    __syncthreads();
+
+    // ---- MFMA: D[cout][pixel] ----
+    f32x16_t acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[mt][j] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t afr = *reinterpret_cast<const bf16x8_t*>(p.wpk + ((ks * 2 + h) * 32 + r) * 8);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int ty = wave * 2 + mt, tx = r;
+            union { bf16x8_t v; bf16_t s[8]; } b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = ks * 16 + h * 8 + j;  // runtime in h only
+                const int kh = k / 9, kr = k - kh * 9;
+                b.s[j] = (k < 27) ? halo[(2 * ty + kh) * ROW + 6 * tx + kr] : (bf16_t)0;
+            }
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, b.v, acc[mt], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue ----
+    unsigned char* stage = smem;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int tp = (wave * 2 + mt) * TW + r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cn = 8 * g + 4 * h;
+            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + cn);
+            const float v0 = apply_act(acc[mt][4 * g + 0] + b4.x, p.act), v1 = apply_act(acc[mt][4 * g + 1] + b4.y, p.act);
+            const float v2 = apply_act(acc[mt][4 * g + 2] + b4.z, p.act), v3 = apply_act(acc[mt][4 * g + 3] + b4.w, p.act);
+            uint2 o;
+            o.x = pack_bf16x2(v0, v1);
+            o.y = pack_bf16x2(v2, v3);
+            *reinterpret_cast<uint2*>(stage + tp * STAGE_PITCH + cn * 2) = o;
+        }
+    }
+    __syncthreads();
+    const int cpp = p.Cout_store / 8;  // 16-byte chunks stored per pixel (1..4)
+    for (int i = tid; i < 256 * cpp; i += 256) {
+        const int tp = i / cpp, ch = i - tp * cpp;
+        const int ty = tp / TW, tx = tp - ty * TW;
+        const int oy = tile_y * TH + ty, ox = tile_x * TW + tx;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + tp * STAGE_PITCH + ch * 16);
+        *reinterpret_cast<uint4*>(p.y + (((size_t)n_img * p.Ho + oy) * p.Wo + ox) * p.Cout_store + ch * 8) = v;
+    }
+}
+
+// standalone normalise: u8 [N,H,W,3] -> bf16 [N,Hp,Wp,4]-free NHWC(3) or NCHW, zero outside (vh, vw)
+__global__ void normalize_kernel(const uint8_t* x, bf16_t* y, int N, int H, int W, int Hp, int Wp, int vh, int vw,
+                                 float s0, float s1, float s2, float b0, float b1, float b2, int nchw) {
+    const size_t total = (size_t)N * Hp * Wp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % Wp);
+        const size_t t = i / Wp;
+        const int yy = (int)(t % Hp), n = (int)(t / Hp);
+        float v[3] = {0.f, 0.f, 0.f};
+        if (yy < vh && xx < vw) {
+            const uint8_t* s = x + (((size_t)n * H + yy) * W + xx) * 3;
+            v[0] = (float)s[0] * s0; v[0] = v[0] + b0;
+            v[1] = (float)s[1] * s1; v[1] = v[1] + b1;
+            v[2] = (float)s[2] * s2; v[2] = v[2] + b2;
+        }
+        if (nchw) {
+            const size_t plane = (size_t)Hp * Wp;
+            bf16_t* d = y + (size_t)n * 3 * plane + (size_t)yy * Wp + xx;
+            d[0] = f32_to_bf16(v[0]); d[plane] = f32_to_bf16(v[1]); d[2 * plane] = f32_to_bf16(v[2]);
+        } else {
+            bf16_t* d = y + i * 3;
+            d[0] = f32_to_bf16(v[0]); d[1] = f32_to_bf16(v[1]); d[2] = f32_to_bf16(v[2]);
+        }
+    }
+}
+
+}  // namespace
+
+void pack_stem_weights(const bf16_t* ohwi, int cout, bf16_t* out /* [2][2][32][8] */) {
+    for (int ks = 0; ks < 2; ++ks)
+        for (int h = 0; h < 2; ++h)
+            for (int co = 0; co < 32; ++co)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = ks * 16 + h * 8 + j;  // k = (kh*3 + kw)*3 + c == OHWI inner order
+                    out[((ks * 2 + h) * 32 + co) * 8 + j] = (co < cout && k < 27) ? ohwi[co * 27 + k] : (bf16_t)0;
+                }
+}
+
+hipError_t stem_conv_launch(const StemParams& p, hipStream_t stream) {
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    hipLaunchKernelGGL(stem_conv_kernel, dim3(p.N * tiles_x * tiles_y), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t normalize_launch(const uint8_t* x, bf16_t* y, int N, int H, int W, int Hp, int Wp, int vh, int vw,
+                            const float* scale, const float* shift, int nchw, hipStream_t stream) {
+    const size_t total = (size_t)N * Hp * Wp;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(normalize_kernel, dim3(grid), dim3(256), 0, stream, x, y, N, H, W, Hp, Wp, vh, vw, scale[0], scale[1],
+                       scale[2], shift[0], shift[1], shift[2], nchw);
+    return hipGetLastError();
+}

@@ -1,0 +1,307 @@
+"""Architecture tables, seeded weights and the weight-blob format of the det+rec engine.
+
+The reference ships no det+rec network: the engine slot is a remote
+call (/root/reference/backend/services/ocr_service.py:213-246) or a third-party VLM
+(/root/reference/backend/services/ocr_service_paddleocr_backup.py:285).  The networks
+here are the ones BASELINE.json names, laid out after the public PaddleOCR model
+definitions (det_r18_vd_db; rec_mv3_none_bilstm_ctc): *defined by this build*.
+
+Everything in this file is host-side plumbing shared by the ctypes host, the C++
+engine (which hard-codes the same layer names) and the test oracle:
+  * DET_LAYERS / REC_* tables  — layer names, shapes, strides, activations
+  * make_det_weights / make_rec_weights — deterministic seeded weights, BN folded
+  * write_blob / read_blob — the "LOCW" weight container the C-ABI loads
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# bf16 helpers (numpy has no bf16: values are kept as float32 that are exactly bf16)
+# --------------------------------------------------------------------------------------
+
+
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """Round float32 -> nearest-even bf16, returned as float32 (exactly representable)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32).reshape(x.shape)
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16).reshape(x.shape)
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    b = np.ascontiguousarray(b, dtype=np.uint16)
+    return (b.astype(np.uint32) << 16).view(np.float32).reshape(b.shape)
+
+
+# --------------------------------------------------------------------------------------
+# Detection: DBNet = ResNet18_vd + DBFPN(256) + DBHead (probability branch)
+# --------------------------------------------------------------------------------------
+# conv entry: (name, cin, cout, k, stride, act, residual_from, kind)
+#   kind: "conv" | "short_vd" (2x2 avg-pool fused as a 2x2/s2 conv) | "convt" (2x2/s2 transposed)
+#   act : "relu" | "none" | "sigmoid"
+DET_MEAN = (0.485, 0.456, 0.406)
+DET_STD = (0.229, 0.224, 0.225)
+DET_STAGE_CH = (64, 128, 256, 512)
+DET_FPN_CH = 256
+DET_THRESH = 0.3
+DET_BOX_THRESH = 0.6
+DET_UNCLIP_RATIO = 1.5
+DET_MIN_SIZE = 3
+DET_MAX_CANDIDATES = 1000
+
+
+def det_conv_table() -> List[dict]:
+    t: List[dict] = []
+
+    def add(name, cin, cout, k, stride, act, kind="conv"):
+        t.append(dict(name=name, cin=cin, cout=cout, k=k, stride=stride, act=act, kind=kind))
+
+    add("stem.conv1", 3, 32, 3, 2, "relu")
+    add("stem.conv2", 32, 32, 3, 1, "relu")
+    add("stem.conv3", 32, 64, 3, 1, "relu")
+    cin = 64
+    for i, ch in enumerate(DET_STAGE_CH):
+        for j in range(2):
+            stride = 2 if (i > 0 and j == 0) else 1
+            add(f"s{i}.b{j}.conv0", cin, ch, 3, stride, "relu")
+            add(f"s{i}.b{j}.conv1", ch, ch, 3, 1, "relu")  # relu applied after the residual add
+            if j == 0:
+                if i == 0:
+                    add(f"s{i}.b{j}.short", cin, ch, 1, 1, "none")
+                else:
+                    add(f"s{i}.b{j}.short", cin, ch, 2, 2, "none", kind="short_vd")
+            cin = ch
+    for lvl, ch in zip((5, 4, 3, 2), reversed(DET_STAGE_CH)):
+        add(f"fpn.in{lvl}", ch, DET_FPN_CH, 1, 1, "none")
+    for lvl in (5, 4, 3, 2):
+        add(f"fpn.p{lvl}", DET_FPN_CH, DET_FPN_CH // 4, 3, 1, "none")
+    add("head.conv1", DET_FPN_CH, 64, 3, 1, "relu")
+    add("head.convt2", 64, 64, 2, 2, "relu", kind="convt")
+    add("head.convt3", 64, 1, 2, 2, "sigmoid", kind="convt")
+    return t
+
+
+def det_macs_per_page(h: int, w: int) -> int:
+    """Algorithmic MACs of one det forward on an h x w page (h, w multiples of 32)."""
+    assert h % 32 == 0 and w % 32 == 0
+    macs = 0
+    res = {"stem.conv1": 2, "stem.conv2": 2, "stem.conv3": 2}
+    for e in det_conv_table():
+        n = e["name"]
+        if n in res:
+            s = res[n]
+        elif n.startswith("s"):
+            s = 4 << int(n[1])
+        elif n.startswith("fpn.in") or n.startswith("fpn.p"):
+            s = 1 << int(n[-1])
+        elif n == "head.conv1":
+            s = 4
+        elif n == "head.convt2":
+            s = 4  # input resolution; 4 output taps each 1x1
+        elif n == "head.convt3":
+            s = 2
+        ho, wo = h // s, w // s
+        taps = e["k"] * e["k"]
+        if e["kind"] == "convt":
+            macs += ho * wo * 4 * e["cin"] * e["cout"]
+        elif e["kind"] == "short_vd":
+            macs += ho * wo * e["cin"] * e["cout"]  # avg-pool + 1x1 (the algorithmic count)
+        else:
+            macs += ho * wo * taps * e["cin"] * e["cout"]
+    return macs
+
+
+# --------------------------------------------------------------------------------------
+# Recognition: CRNN = MobileNetV3-small x0.5 -> 2 x BiLSTM(96) -> FC -> CTC greedy
+# --------------------------------------------------------------------------------------
+REC_H, REC_W, REC_T = 32, 320, 80
+REC_HIDDEN = 96
+REC_FEAT = 288
+
+
+def _make_div(v: float, d: int = 8) -> int:
+    nv = max(d, int(v + d / 2) // d * d)
+    if nv < 0.9 * v:
+        nv += d
+    return nv
+
+
+# (k, exp, c, se, act, stride_h) at scale 1.0; width stride is always 1
+_MV3_SMALL = [
+    (3, 16, 16, True, "relu", 1),
+    (3, 72, 24, False, "relu", 2),
+    (3, 88, 24, False, "relu", 1),
+    (5, 96, 40, True, "hswish", 2),
+    (5, 240, 40, True, "hswish", 1),
+    (5, 240, 40, True, "hswish", 1),
+    (5, 120, 48, True, "hswish", 1),
+    (5, 144, 48, True, "hswish", 1),
+    (5, 288, 96, True, "hswish", 2),
+    (5, 576, 96, True, "hswish", 1),
+    (5, 576, 96, True, "hswish", 1),
+]
+
+
+def rec_block_table(scale: float = 0.5) -> List[dict]:
+    blocks = []
+    cin = _make_div(16 * scale)
+    for i, (k, exp, c, se, act, sh) in enumerate(_MV3_SMALL):
+        e, co = _make_div(exp * scale), _make_div(c * scale)
+        blocks.append(dict(idx=i, k=k, cin=cin, exp=e, cout=co, se=se, act=act, stride_h=sh,
+                           res=(sh == 1 and cin == co), se_mid=e // 4))
+        cin = co
+    return blocks
+
+
+def rec_stem_ch(scale: float = 0.5) -> int:
+    return _make_div(16 * scale)
+
+
+# --------------------------------------------------------------------------------------
+# CTC dictionary (the PP-OCR key file is absent offline: the build ships its own list)
+# --------------------------------------------------------------------------------------
+
+
+def ctc_charset(num_classes: int = 6625) -> List[str]:
+    """index 0 = blank, last index = space (PP-OCR `use_space_char` convention)."""
+    n_chars = num_classes - 2
+    chars = [chr(c) for c in range(0x21, 0x7F)]
+    cp = 0x4E00
+    while len(chars) < n_chars:
+        chars.append(chr(cp))
+        cp += 1
+    return ["\x00"] + chars[:n_chars] + [" "]
+
+
+def devanagari_charset() -> List[str]:
+    """blank + Devanagari block + digits/latin punctuation + space (config 5; build's own list)."""
+    chars = [chr(c) for c in range(0x0900, 0x0980)] + [chr(c) for c in range(0x21, 0x7F) if not chr(c).isalpha()]
+    return ["\x00"] + chars + [" "]
+
+
+# --------------------------------------------------------------------------------------
+# Seeded weights (BN folded into conv weight + bias; conv weights are bf16-exact float32)
+# --------------------------------------------------------------------------------------
+
+
+def _he(rng, cout, k, cin, gain=1.0, depthwise=False):
+    fan_in = k * k * (1 if depthwise else cin)
+    w = rng.standard_normal((cout, k, k, cin), dtype=np.float32) * np.float32(gain * np.sqrt(2.0 / fan_in))
+    return bf16_round(w)
+
+
+def make_det_weights(seed: int = 1234) -> Dict[str, np.ndarray]:
+    """name.w: OHWI float32 (bf16-exact), name.b: float32 [cout]. convT: [(dy*2+dx)*cout+co][cin]."""
+    rng = np.random.default_rng(seed)
+    w: Dict[str, np.ndarray] = {}
+    for e in det_conv_table():
+        n, cin, cout, k = e["name"], e["cin"], e["cout"], e["k"]
+        gain = 1.0
+        if n.endswith(".conv1") and n.startswith("s"):
+            gain = 0.5  # second conv of a residual branch
+        if n.endswith(".short"):
+            gain = 0.7071
+        if n.startswith("fpn."):
+            gain = 0.7071
+        if e["kind"] == "convt":
+            fan_in = cin
+            wt = rng.standard_normal((4 * cout, 1, 1, cin), dtype=np.float32) * np.float32(np.sqrt(2.0 / fan_in))
+            w[n + ".w"] = bf16_round(wt)
+        elif e["kind"] == "short_vd":
+            base = rng.standard_normal((cout, 1, 1, cin), dtype=np.float32) * np.float32(gain * np.sqrt(2.0 / cin))
+            base = bf16_round(base)  # the 1x1 weight; the fused 2x2 taps are base/4 (exact in bf16)
+            w[n + ".w"] = np.broadcast_to(base / 4.0, (cout, 2, 2, cin)).astype(np.float32).copy()
+        else:
+            w[n + ".w"] = _he(rng, cout, k, cin, gain)
+        b = rng.standard_normal(cout, dtype=np.float32) * np.float32(0.05)
+        if n.startswith("fpn."):
+            b[:] = 0.0  # DBFPN convs carry no bias / BN
+        if n == "head.convt3":
+            b[:] = np.float32(-0.5)
+        w[n + ".b"] = b.astype(np.float32)
+    return w
+
+
+def make_rec_weights(seed: int = 4321, num_classes: int = 6625, scale: float = 0.5) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    w: Dict[str, np.ndarray] = {}
+
+    def conv(name, cout, k, cin, gain=1.0, depthwise=False):
+        w[name + ".w"] = _he(rng, cout, k, 1 if depthwise else cin, gain, depthwise)
+        w[name + ".b"] = (rng.standard_normal(cout, dtype=np.float32) * np.float32(0.05)).astype(np.float32)
+
+    c0 = rec_stem_ch(scale)
+    conv("rec.conv1", c0, 3, 3)
+    for b in rec_block_table(scale):
+        p = f"rec.b{b['idx']}"
+        conv(p + ".expand", b["exp"], 1, b["cin"])
+        conv(p + ".dw", b["exp"], b["k"], b["exp"], depthwise=True)
+        if b["se"]:
+            conv(p + ".se1", b["se_mid"], 1, b["exp"])
+            conv(p + ".se2", b["exp"], 1, b["se_mid"], gain=0.7071)
+        conv(p + ".project", b["cout"], 1, b["exp"], gain=0.7071)
+    conv("rec.conv2", REC_FEAT, 1, rec_block_table(scale)[-1]["cout"])
+    h = REC_HIDDEN
+    for layer, din in ((0, REC_FEAT), (1, 2 * h)):
+        for d in ("fw", "bw"):
+            p = f"lstm.l{layer}.{d}"
+            w[p + ".w_ih"] = bf16_round(rng.uniform(-1, 1, (4 * h, din)).astype(np.float32) * np.float32(1.0 / np.sqrt(h)))
+            w[p + ".w_hh"] = bf16_round(rng.uniform(-1, 1, (4 * h, h)).astype(np.float32) * np.float32(1.0 / np.sqrt(h)))
+            w[p + ".b"] = (rng.uniform(-1, 1, 4 * h).astype(np.float32) * np.float32(1.0 / np.sqrt(h))).astype(np.float32)
+    w["ctc.fc.w"] = bf16_round(rng.standard_normal((num_classes, 2 * h), dtype=np.float32) * np.float32(4.0 / np.sqrt(2 * h)))
+    w["ctc.fc.b"] = (rng.standard_normal(num_classes, dtype=np.float32) * np.float32(0.1)).astype(np.float32)
+    return w
+
+
+# --------------------------------------------------------------------------------------
+# "LOCW" weight container
+#   header : b"LOCW", u32 version(1), u32 n_tensors
+#   tensor : u16 name_len, name, u8 dtype(0=f32,1=bf16), u8 ndim, u32 dims[ndim], u64 nbytes,
+#            pad to 16-byte file offset, raw data
+# --------------------------------------------------------------------------------------
+BLOB_MAGIC = b"LOCW"
+
+
+def write_blob(weights: Dict[str, np.ndarray]) -> bytes:
+    out = bytearray()
+    out += BLOB_MAGIC + struct.pack("<II", 1, len(weights))
+    for name, arr in weights.items():
+        nb = name.encode()
+        as_bf16 = name.endswith(".w") or name.endswith(".w_ih") or name.endswith(".w_hh")
+        data = f32_to_bf16_bits(arr).tobytes() if as_bf16 else np.ascontiguousarray(arr, np.float32).tobytes()
+        out += struct.pack("<H", len(nb)) + nb + struct.pack("<BB", 1 if as_bf16 else 0, arr.ndim)
+        out += struct.pack("<%dI" % arr.ndim, *arr.shape) + struct.pack("<Q", len(data))
+        out += b"\x00" * ((-len(out)) % 16)
+        out += data
+    return bytes(out)
+
+
+def read_blob(blob: bytes) -> Dict[str, np.ndarray]:
+    assert blob[:4] == BLOB_MAGIC, "not a LOCW blob"
+    ver, n = struct.unpack_from("<II", blob, 4)
+    assert ver == 1
+    off = 12
+    out: Dict[str, np.ndarray] = {}
+    for _ in range(n):
+        (ln,) = struct.unpack_from("<H", blob, off); off += 2
+        name = blob[off:off + ln].decode(); off += ln
+        dt, nd = struct.unpack_from("<BB", blob, off); off += 2
+        dims = struct.unpack_from("<%dI" % nd, blob, off); off += 4 * nd
+        (nbytes,) = struct.unpack_from("<Q", blob, off); off += 8
+        off += (-off) % 16
+        raw = blob[off:off + nbytes]; off += nbytes
+        if dt == 1:
+            out[name] = bf16_bits_to_f32(np.frombuffer(raw, np.uint16).reshape(dims))
+        else:
+            out[name] = np.frombuffer(raw, np.float32).reshape(dims).copy()
+    return out

@@ -1,0 +1,265 @@
+"""ctypes binding of liblumina_ocr.so (include/lumina_ocr.h) — the only way the host reaches the GPU.
+
+PyTorch-ROCm is used for device memory and streams only (tensor.data_ptr(), current stream);
+no torch op runs on the hot path.  There is NO CPU fallback: a missing library or device raises
+EngineUnavailable, which the provider turns into an error *result* (the reference's convention,
+/root/reference/backend/services/ocr_service.py:464-475).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import arch
+
+_LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "liblumina_ocr.so"
+
+REC_H, REC_W, REC_T = 32, 320, 80
+MAX_BOXES = 1000
+
+
+class EngineUnavailable(RuntimeError):
+    pass
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load the HIP engine; fails loudly when it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("LUMINA_OCR_LIB", str(_LIB_PATH)))
+    if not path.exists():
+        raise EngineUnavailable(f"{path} not found: build it with `make -C ocr-system_amd` (hipcc, gfx950)")
+    lib = ctypes.CDLL(str(path))
+    c = ctypes
+    vp, i32, f32, sz = c.c_void_p, c.c_int, c.c_float, c.c_size_t
+    sig = {
+        "lumina_ocr_create": (i32, [i32, c.POINTER(vp)]),
+        "lumina_ocr_destroy": (None, [vp]),
+        "lumina_ocr_last_error": (c.c_char_p, [vp]),
+        "lumina_ocr_version": (c.c_char_p, []),
+        "lumina_ocr_set_option": (i32, [vp, c.c_char_p, i32]),
+        "lumina_ocr_load_det_weights": (i32, [vp, vp, sz]),
+        "lumina_ocr_load_rec_weights": (i32, [vp, vp, sz]),
+        "lumina_ocr_num_classes": (i32, [vp]),
+        "lumina_ocr_normalize": (i32, [vp, vp, i32, i32, i32, i32, i32, c.POINTER(f32), c.POINTER(f32), i32, vp, vp]),
+        "lumina_ocr_det_forward": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+        "lumina_ocr_det_postprocess": (i32, [vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, i32, i32, vp, vp, vp, vp]),
+        "lumina_ocr_rec_crop": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp]),
+        "lumina_ocr_rec_forward": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+        "lumina_ocr_ctc_decode": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
+        "lumina_ocr_conv2d": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+        "lumina_ocr_read_tap": (i32, [vp, c.c_char_p, vp, sz, c.POINTER(i32)]),
+        "lumina_ocr_conv_timing": (i32, [vp, c.POINTER(c.c_double), c.POINTER(c.c_double), c.POINTER(i32)]),
+        "lumina_ocr_resize_lanczos": (i32, [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
+        "lumina_ocr_enhance": (i32, [vp, vp, i32, i32, i32, f32, f32, vp, vp]),
+    }
+    missing = []
+    for name, (res, args) in sig.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    lib._missing = missing  # exported-symbol check lives in tests/test_abi.py
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "lumina_ocr_create", "lumina_ocr_destroy", "lumina_ocr_last_error", "lumina_ocr_version", "lumina_ocr_set_option",
+    "lumina_ocr_load_det_weights", "lumina_ocr_load_rec_weights", "lumina_ocr_num_classes", "lumina_ocr_normalize",
+    "lumina_ocr_det_forward", "lumina_ocr_det_postprocess", "lumina_ocr_rec_crop", "lumina_ocr_rec_forward",
+    "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing",
+    "lumina_ocr_resize_lanczos", "lumina_ocr_enhance",
+]
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+class Engine:
+    """One engine handle == one GPU.  Not re-entrant (the reference serialises pages the same way)."""
+
+    def __init__(self, device: int = 0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise EngineUnavailable("no ROCm device visible to torch (torch.cuda.is_available() is False)")
+        self.lib = load_library()
+        self.device = device
+        torch.cuda.set_device(device)
+        h = ctypes.c_void_p()
+        rc = self.lib.lumina_ocr_create(device, ctypes.byref(h))
+        self._h = h
+        if rc != 0:
+            msg = self.lib.lumina_ocr_last_error(h).decode() if h else "create failed"
+            raise EngineUnavailable(msg)
+        self.num_classes = 0
+        self.det_loaded = self.rec_loaded = False
+
+    # -- plumbing -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.lumina_ocr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise EngineError(self.lib.lumina_ocr_last_error(self._h).decode())
+
+    def _stream(self) -> int:
+        return _torch().cuda.current_stream().cuda_stream
+
+    def set_option(self, key: str, value: int):
+        self._chk(self.lib.lumina_ocr_set_option(self._h, key.encode(), int(value)))
+
+    def version(self) -> str:
+        return self.lib.lumina_ocr_version().decode()
+
+    # -- weights --------------------------------------------------------------------------
+    def load_det(self, weights):
+        blob = weights if isinstance(weights, (bytes, bytearray)) else arch.write_blob(weights)
+        buf = ctypes.create_string_buffer(bytes(blob), len(blob))
+        self._chk(self.lib.lumina_ocr_load_det_weights(self._h, ctypes.cast(buf, ctypes.c_void_p), len(blob)))
+        self.det_loaded = True
+
+    def load_rec(self, weights):
+        blob = weights if isinstance(weights, (bytes, bytearray)) else arch.write_blob(weights)
+        buf = ctypes.create_string_buffer(bytes(blob), len(blob))
+        self._chk(self.lib.lumina_ocr_load_rec_weights(self._h, ctypes.cast(buf, ctypes.c_void_p), len(blob)))
+        self.num_classes = self.lib.lumina_ocr_num_classes(self._h)
+        self.rec_loaded = True
+
+    # -- hot path -------------------------------------------------------------------------
+    def normalize(self, img, hp: int, wp: int, scale, shift, nchw: bool = False):
+        torch = _torch()
+        n, h, w, _ = img.shape
+        out = torch.empty((n, 3, hp, wp) if nchw else (n, hp, wp, 3), dtype=torch.bfloat16, device=img.device)
+        sc = (ctypes.c_float * 3)(*scale)
+        sh = (ctypes.c_float * 3)(*shift)
+        self._chk(self.lib.lumina_ocr_normalize(self._h, _ptr(img), n, h, w, hp, wp, sc, sh, int(nchw), _ptr(out), self._stream()))
+        return out
+
+    def det_forward(self, pages, hp: Optional[int] = None, wp: Optional[int] = None, out=None):
+        """pages uint8 [B,H,W,3] (device) -> probability map bf16 [B,Hp,Wp]."""
+        torch = _torch()
+        assert pages.dtype == torch.uint8 and pages.is_cuda and pages.is_contiguous() and pages.shape[-1] == 3
+        b, h, w, _ = pages.shape
+        hp = hp or (h + 31) // 32 * 32
+        wp = wp or (w + 31) // 32 * 32
+        if out is None:
+            out = torch.empty((b, hp, wp), dtype=torch.bfloat16, device=pages.device)
+        self._chk(self.lib.lumina_ocr_det_forward(self._h, _ptr(pages), b, h, w, hp, wp, _ptr(out), self._stream()))
+        return out
+
+    def det_postprocess(self, prob, valid_h: int, valid_w: int, thresh=arch.DET_THRESH, box_thresh=arch.DET_BOX_THRESH,
+                        unclip_ratio=arch.DET_UNCLIP_RATIO, min_size=arch.DET_MIN_SIZE, max_boxes=MAX_BOXES):
+        torch = _torch()
+        b, hp, wp = prob.shape
+        boxes = torch.zeros((b, max_boxes, 8), dtype=torch.int32, device=prob.device)
+        scores = torch.zeros((b, max_boxes), dtype=torch.float32, device=prob.device)
+        counts = torch.zeros((b,), dtype=torch.int32, device=prob.device)
+        self._chk(self.lib.lumina_ocr_det_postprocess(self._h, _ptr(prob), b, hp, wp, valid_h, valid_w, thresh, box_thresh,
+                                                      unclip_ratio, min_size, max_boxes, _ptr(boxes), _ptr(scores), _ptr(counts),
+                                                      self._stream()))
+        return boxes, scores, counts
+
+    def rec_crop(self, pages, quads, page_idx):
+        torch = _torch()
+        b, h, w, _ = pages.shape
+        n = quads.shape[0]
+        crops = torch.empty((n, REC_H, REC_W, 3), dtype=torch.uint8, device=pages.device)
+        widths = torch.empty((n,), dtype=torch.int32, device=pages.device)
+        if n:
+            self._chk(self.lib.lumina_ocr_rec_crop(self._h, _ptr(pages), b, h, w, _ptr(quads), _ptr(page_idx), n, _ptr(crops),
+                                                   _ptr(widths), self._stream()))
+        return crops, widths
+
+    def rec_forward(self, crops, widths=None):
+        torch = _torch()
+        n = crops.shape[0]
+        idx = torch.empty((n, REC_T), dtype=torch.int32, device=crops.device)
+        prob = torch.empty((n, REC_T), dtype=torch.float32, device=crops.device)
+        if n:
+            self._chk(self.lib.lumina_ocr_rec_forward(self._h, _ptr(crops), _ptr(widths), n, _ptr(idx), _ptr(prob), self._stream()))
+        return idx, prob
+
+    def ctc_decode(self, idx, prob):
+        torch = _torch()
+        n = idx.shape[0]
+        text = torch.empty((n, REC_T), dtype=torch.int32, device=idx.device)
+        length = torch.empty((n,), dtype=torch.int32, device=idx.device)
+        score = torch.empty((n,), dtype=torch.float32, device=idx.device)
+        if n:
+            self._chk(self.lib.lumina_ocr_ctc_decode(self._h, _ptr(idx), _ptr(prob), n, _ptr(text), _ptr(length), _ptr(score),
+                                                     self._stream()))
+        return text, length, score
+
+    # -- kernel-level ---------------------------------------------------------------------
+    def conv2d(self, x, w_ohwi_f32: np.ndarray, bias: np.ndarray, ks: int, stride: int, act: int = 0, res=None):
+        """x bf16 [N,H,W,Cin] device; weights OHWI float32 (bf16-exact) host -> y bf16 [N,Ho,Wo,Cout]."""
+        torch = _torch()
+        n, h, w, cin = x.shape
+        cout = w_ohwi_f32.shape[0]
+        ho = (h - 1) // stride + 1 if ks == 3 else h // stride
+        wo = (w - 1) // stride + 1 if ks == 3 else w // stride
+        y = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x.device)
+        wb = np.ascontiguousarray(arch.f32_to_bf16_bits(w_ohwi_f32))
+        bb = np.ascontiguousarray(bias, np.float32)
+        self._chk(self.lib.lumina_ocr_conv2d(self._h, _ptr(x), n, h, w, cin, wb.ctypes.data, bb.ctypes.data, cout, ks, stride, act,
+                                             _ptr(res), _ptr(y), self._stream()))
+        return y
+
+    def read_tap(self, name: str) -> np.ndarray:
+        dims = (ctypes.c_int * 4)()
+        self._chk(self.lib.lumina_ocr_read_tap(self._h, name.encode(), None, 0, dims))
+        n = int(np.prod(list(dims)))
+        buf = np.empty(n, np.uint16)
+        self._chk(self.lib.lumina_ocr_read_tap(self._h, name.encode(), buf.ctypes.data, n, dims))
+        return arch.bf16_bits_to_f32(buf).reshape(tuple(dims))
+
+    def conv_timing(self) -> Tuple[float, float, int]:
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        self._chk(self.lib.lumina_ocr_conv_timing(self._h, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)))
+        return ms.value, fl.value, n.value
+
+    # -- pre-processing on device (image_preprocessing.py:81-110, :132-158) -----------------
+    def resize_lanczos(self, img, out_h: int, out_w: int):
+        torch = _torch()
+        n, h, w, c = img.shape
+        out = torch.empty((n, out_h, out_w, c), dtype=torch.uint8, device=img.device)
+        self._chk(self.lib.lumina_ocr_resize_lanczos(self._h, _ptr(img), n, h, w, c, _ptr(out), out_h, out_w, self._stream()))
+        return out
+
+    def enhance(self, img, contrast: float = 1.2, sharpness: float = 1.1):
+        torch = _torch()
+        n, h, w, c = img.shape
+        out = torch.empty_like(img)
+        tmp = torch.empty_like(img)
+        self._chk(self.lib.lumina_ocr_enhance(self._h, _ptr(img), n, h, w, contrast, sharpness, _ptr(tmp), _ptr(out)))
+        return out

@@ -1,0 +1,20 @@
+"""CPU oracle for the Lumina OCR hot path — TEST INFRASTRUCTURE, not product code.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package; the product (ocr-system_amd/) never does, and fails loudly when its HIP library is
+missing.
+
+Parity status:
+  * pre/post-processing restatements (resize, enhance, reading order, box matcher, schema)
+    are PINNED by golden vectors captured from the importable reference modules
+    (tests/golden/, generator tools/make_golden.py).
+  * det+rec numerics (DBNet, DB post-process, crop, CRNN, CTC) have NO reference
+    implementation, weights, dictionaries or test images offline: "parity unpinned".
+    The restatement below is the definition the HIP path is checked against.
+"""
+import sys as _sys
+from pathlib import Path as _Path
+
+_pkg = str(_Path(__file__).resolve().parent.parent / "ocr-system_amd")
+if _pkg not in _sys.path:
+    _sys.path.insert(0, _pkg)

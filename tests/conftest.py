@@ -1,0 +1,44 @@
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT, ROOT / "ocr-system_amd"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def engine():
+    from lumina_ocr.engine import Engine
+    eng = Engine(0)
+    yield eng
+    eng.close()
+
+
+@pytest.fixture(scope="session")
+def det_weights():
+    from lumina_ocr import arch
+    return arch.make_det_weights(1234)
+
+
+@pytest.fixture(scope="session")
+def rec_weights():
+    from lumina_ocr import arch
+    return arch.make_rec_weights(4321)
+
+
+def close_stats(got: np.ndarray, ref: np.ndarray):
+    """bf16-aware comparison: share within 1 / 4 bf16 ulps, max abs error, mean abs error."""
+    got = np.asarray(got, np.float32).ravel()
+    ref = np.asarray(ref, np.float32).ravel()
+    err = np.abs(got - ref)
+    ulp = np.maximum(np.abs(ref), 2.0 ** -6) * 2.0 ** -7  # one bf16 ulp at |ref| (floored)
+    return dict(within1=float((err <= ulp).mean()), within4=float((err <= 4 * ulp).mean()), max_abs=float(err.max()),
+                mean_abs=float(err.mean()), ref_mean_abs=float(np.abs(ref).mean()))

@@ -1,0 +1,123 @@
+"""GPU parity: DBNet forward through the C ABI vs the oracle restatement (oracle/nets.py, mode bf16),
+layer by layer (taps) and on the final probability map; then DB post-process vs the C oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import close_stats
+from lumina_ocr import arch, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pages(b, h, w, seed):
+    return np.stack([synth.synth_page(h, w, seed + i, n_lines=max(3, h // 40))[0] for i in range(b)])
+
+
+@pytest.mark.parametrize("shape", [(2, 250, 200), (1, 320, 448), (3, 96, 130)], ids=lambda s: "b%d_%dx%d" % s)
+def test_det_forward_taps_and_prob(engine, det_weights, shape):
+    from oracle import nets
+    b, h, w = shape
+    pages = _pages(b, h, w, 7)
+    engine.load_det(det_weights)
+    engine.set_option("keep_taps", 1)
+    engine.set_option("det_sub_batch", 8)
+    prob = engine.det_forward(torch.from_numpy(pages).cuda())
+    torch.cuda.synchronize()
+    taps = {}
+    ref = nets.det_forward(det_weights, pages, mode="bf16", taps=taps)
+    worst = {}
+    for name in ["stem.conv1", "stem.conv2", "stem.conv3", "stem.pool", "s0.b0", "s0.b1", "s1.b0", "s1.b1", "s2.b0", "s2.b1",
+                 "s3.b0", "s3.b1", "fpn.fuse", "head.conv1", "head.convt2"]:
+        got = engine.read_tap(name)
+        assert got.shape == taps[name].shape, (name, got.shape, taps[name].shape)
+        st = close_stats(got, taps[name])
+        worst[name] = st
+        # identical arithmetic definition; only the fp32 summation order differs, so almost every value is
+        # bit-equal and the rest are off by a bf16 ulp that then propagates
+        assert st["within1"] > 0.99 and st["mean_abs"] < 0.004 * max(st["ref_mean_abs"], 1e-3), (name, st)
+    engine.set_option("keep_taps", 0)
+    p = prob.float().cpu().numpy()
+    st = close_stats(p, ref)
+    assert p.shape == ref.shape
+    assert st["within4"] > 0.995 and st["max_abs"] < 0.05, st
+    flips = float(((p > arch.DET_THRESH) != (ref > arch.DET_THRESH)).mean())
+    assert flips < 2e-3, flips
+
+
+def test_det_sub_batching_is_invisible(engine, det_weights):
+    pages = torch.from_numpy(_pages(5, 128, 160, 3)).cuda()
+    engine.load_det(det_weights)
+    engine.set_option("det_sub_batch", 8)
+    a = engine.det_forward(pages).clone()
+    engine.set_option("det_sub_batch", 2)
+    b = engine.det_forward(pages).clone()
+    engine.set_option("det_sub_batch", 4)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+def test_normalize_kernel_bit_exact(engine):
+    from oracle import nets
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (2, 37, 53, 3), dtype=np.uint8)
+    mean, std = np.asarray(arch.DET_MEAN, np.float32), np.asarray(arch.DET_STD, np.float32)
+    scale = (np.float32(1.0) / (np.float32(255.0) * std)).astype(np.float32)
+    shift = (-mean / std).astype(np.float32)
+    out = engine.normalize(torch.from_numpy(img).cuda(), 64, 64, scale.tolist(), shift.tolist(), nchw=True)
+    ref = nets.det_normalize(img, 64, 64).numpy()
+    assert np.array_equal(out.float().cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_db_postprocess_bit_exact_on_engine_prob(engine, det_weights, seed):
+    """Integer path: feed the SAME bf16 probability map to the HIP post-process and to the C oracle."""
+    from oracle import dbpost
+    b, h, w = 2, 300, 420
+    pages = _pages(b, h, w, 11 + seed)
+    engine.load_det(det_weights)
+    prob = engine.det_forward(torch.from_numpy(pages).cuda())
+    boxes, scores, counts = engine.det_postprocess(prob, h, w)
+    torch.cuda.synchronize()
+    pb = prob.view(torch.int16).cpu().numpy().view(np.uint16)
+    for i in range(b):
+        rb, rs, ncomp = dbpost.db_postprocess(pb[i], h, w)
+        n = int(counts[i])
+        assert n == len(rb), (n, len(rb), ncomp)
+        assert np.array_equal(boxes[i, :n].cpu().numpy(), rb)
+        assert np.array_equal(scores[i, :n].cpu().numpy(), rs)
+
+
+def test_db_postprocess_structured_maps(engine):
+    """Hand-made probability maps: rotated bars, touching blobs, 1-pixel specks, blobs on the border, > cap."""
+    from oracle import dbpost
+    rng = np.random.default_rng(3)
+    hp, wp, vh, vw = 256, 320, 250, 310
+    maps = []
+    yy, xx = np.mgrid[0:hp, 0:wp]
+    for k in range(4):
+        p = rng.random((hp, wp), dtype=np.float32) * 0.25
+        for _ in range(14):
+            cx, cy = rng.uniform(0, wp), rng.uniform(0, hp)
+            ang = rng.uniform(-1.5, 1.5)
+            hl, hw = rng.uniform(8, 90), rng.uniform(2, 14)
+            u = (xx - cx) * np.cos(ang) + (yy - cy) * np.sin(ang)
+            v = -(xx - cx) * np.sin(ang) + (yy - cy) * np.cos(ang)
+            p[(np.abs(u) < hl) & (np.abs(v) < hw)] = rng.uniform(0.5, 1.0)
+        if k == 3:  # speckle: thousands of tiny components, more than max_candidates
+            p[rng.random((hp, wp)) > 0.97] = 0.9
+        maps.append(p)
+    prob = np.stack(maps)
+    bits = arch.f32_to_bf16_bits(prob)
+    pd = torch.from_numpy(bits.view(np.int16)).cuda().view(torch.bfloat16)
+    boxes, scores, counts = engine.det_postprocess(pd, vh, vw)
+    torch.cuda.synchronize()
+    total = 0
+    for i in range(len(maps)):
+        rb, rs, ncomp = dbpost.db_postprocess(bits[i], vh, vw)
+        n = int(counts[i])
+        assert n == len(rb), (i, n, len(rb), ncomp)
+        assert np.array_equal(boxes[i, :n].cpu().numpy(), rb), i
+        assert np.array_equal(scores[i, :n].cpu().numpy(), rs), i
+        total += n
+    assert total > 20

@@ -1,0 +1,103 @@
+"""GPU parity: CRNN forward + CTC (fused FC/argmax/softmax) + greedy collapse + crop, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import close_stats
+from lumina_ocr import arch, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _crops(n, seed):
+    rng = np.random.default_rng(seed)
+    return np.stack([synth.synth_crop(rng)[0] for _ in range(n)])
+
+
+def test_rec_forward_taps(engine, rec_weights):
+    from oracle import nets
+    crops = _crops(6, 4321)
+    widths = np.array([320, 320, 200, 77, 320, 131], np.int32)
+    crops_m = crops.copy()
+    engine.load_rec(rec_weights)
+    engine.set_option("keep_taps", 1)
+    idx, prob = engine.rec_forward(torch.from_numpy(crops).cuda(), torch.from_numpy(widths).cuda())
+    torch.cuda.synchronize()
+    # oracle: columns >= width are zero in normalised space
+    taps = {}
+    x = nets.rec_normalize(crops_m)
+    for i, wv in enumerate(widths):
+        x[i, :, :, wv:] = 0
+    with torch.no_grad():
+        feat = nets.rec_backbone(rec_weights, x, "bf16", taps)
+        ridx, rprob, logits, seq = nets.rec_head(rec_weights, feat)
+    for name in ["rec.conv1"] + ["rec.b%d" % i for i in range(11)] + ["rec.conv2"]:
+        got = engine.read_tap(name)
+        ref = taps[name]
+        got = got[..., : ref.shape[-1]]  # drop channel padding
+        st = close_stats(got, ref)
+        assert st["within1"] > 0.98 and st["mean_abs"] < 0.01 * max(st["ref_mean_abs"], 1e-3), (name, st)
+    got = engine.read_tap("lstm.l1").reshape(6, 80, 192)
+    st = close_stats(got, seq)
+    assert st["within4"] > 0.97, st
+    engine.set_option("keep_taps", 0)
+    agree = float((idx.cpu().numpy() == ridx).mean())
+    assert agree > 0.9, agree
+    same = idx.cpu().numpy() == ridx
+    assert np.allclose(prob.cpu().numpy()[same], rprob[same], rtol=0.05, atol=1e-6)
+
+
+def test_ctc_fc_argmax_exact_on_same_sequence(engine, rec_weights):
+    """The fused FC+argmax+softmax kernel vs numpy on the engine's own bf16 LSTM output (same inputs)."""
+    crops = _crops(5, 99)
+    engine.load_rec(rec_weights)
+    engine.set_option("keep_taps", 1)
+    idx, prob = engine.rec_forward(torch.from_numpy(crops).cuda())
+    torch.cuda.synchronize()
+    seq = engine.read_tap("lstm.l1").reshape(-1, 192).astype(np.float64)
+    engine.set_option("keep_taps", 0)
+    logits = seq @ rec_weights["ctc.fc.w"].astype(np.float64).T + rec_weights["ctc.fc.b"].astype(np.float64)
+    ref_idx = logits.argmax(1)
+    srt = np.sort(logits, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-4  # fp32 accumulation can only flip near-ties
+    got = idx.cpu().numpy().reshape(-1)
+    assert clear.mean() > 0.95
+    assert np.array_equal(got[clear], ref_idx[clear])
+    ref_p = 1.0 / np.exp(logits - logits.max(1, keepdims=True)).sum(1)
+    assert np.allclose(prob.cpu().numpy().reshape(-1)[clear], ref_p[clear], rtol=2e-4)
+
+
+def test_ctc_decode_bit_exact(engine):
+    from oracle import nets
+    rng = np.random.default_rng(0)
+    n, t = 37, 80
+    idx = rng.integers(0, 6, (n, t)).astype(np.int32)  # many blanks and repeats
+    idx[0] = 0
+    idx[1] = 3
+    idx[2, ::2] = 0
+    prob = rng.random((n, t), dtype=np.float32)
+    text, length, score = engine.ctc_decode(torch.from_numpy(idx).cuda(), torch.from_numpy(prob).cuda())
+    torch.cuda.synchronize()
+    cs = [chr(65 + i) for i in range(6)]
+    ref = nets.ctc_greedy(idx, prob, cs)
+    for i in range(n):
+        ln = int(length[i])
+        got = "".join(cs[k] for k in text[i, :ln].cpu().tolist())
+        assert got == ref[i][0]
+        assert np.float32(score[i].item()) == np.float32(ref[i][1]), (i, score[i].item(), ref[i][1])
+        assert (text[i, ln:] == -1).all()
+
+
+def test_rec_crop_bit_exact(engine):
+    from oracle import dbpost
+    rng = np.random.default_rng(1)
+    pages = rng.integers(0, 256, (2, 180, 260, 3), dtype=np.uint8)
+    quads = np.array([[10, 20, 200, 24, 199, 50, 9, 46], [30, 10, 60, 12, 50, 170, 20, 168], [0, 0, 260, 0, 260, 180, 0, 180],
+                      [100, 100, 140, 100, 140, 108, 100, 108], [250, 170, 270, 172, 268, 190, 248, 188], [5, 5, 5, 5, 5, 5, 5, 5]], np.int32)
+    pidx = np.array([0, 1, 1, 0, 1, 0], np.int32)
+    crops, widths = engine.rec_crop(torch.from_numpy(pages).cuda(), torch.from_numpy(quads).cuda(), torch.from_numpy(pidx).cuda())
+    torch.cuda.synchronize()
+    for i in range(len(quads)):
+        ref, wc = dbpost.rec_crop(pages[pidx[i]], quads[i])
+        assert int(widths[i]) == wc, (i, int(widths[i]), wc)
+        assert np.array_equal(crops[i].cpu().numpy(), ref), i
