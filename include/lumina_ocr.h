@@ -82,6 +82,15 @@ int lumina_ocr_rec_forward(lumina_ocr_t* h, const uint8_t* crops_dev, const int3
 int lumina_ocr_ctc_decode(lumina_ocr_t* h, const int32_t* idx_dev, const float* prob_dev, int n, int32_t* text_dev, int32_t* len_dev,
                           float* score_dev, void* stream);
 
+/* Reference pre-processing on the device, byte-exact with the reference's PIL path:
+ * resize_if_needed (image_preprocessing.py:81-110): 8-bit two-pass LANCZOS to (out_h, out_w); any channel count. */
+int lumina_ocr_resize_lanczos(lumina_ocr_t* h, const uint8_t* in_dev, int n, int height, int width, int channels, uint8_t* out_dev,
+                              int out_h, int out_w, void* stream);
+/* enhance_contrast(contrast) then enhance_sharpness(sharpness) (image_preprocessing.py:132-158, :234-240) on RGB
+ * uint8 [n,H,W,3]; tmp_dev is a scratch buffer of the same size. */
+int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, float contrast, float sharpness,
+                       uint8_t* tmp_dev, uint8_t* out_dev, void* stream);
+
 /* ---- kernel-level entry points (parity tests, benchmarks) ---- */
 /* Generic NHWC bf16 convolution through the MFMA implicit-GEMM kernel.  w_host: OHWI bf16 bits
  * [cout][ks][ks][cin], bias_host float [cout]; ks/stride in {1/1, 2/2, 3/1, 3/2}; cin % 16 == 0,
@@ -95,6 +104,8 @@ int lumina_ocr_conv2d(lumina_ocr_t* h, const uint16_t* x_dev, int n, int height,
 int lumina_ocr_read_tap(lumina_ocr_t* h, const char* name, uint16_t* out_host, size_t capacity_elems, int dims[4]);
 /* Sum of conv-kernel device time (ms) and algorithmic FLOPs since the last call (option time_convs=1). */
 int lumina_ocr_conv_timing(lumina_ocr_t* h, double* total_ms, double* total_flops, int* launches);
+/* Same, per launch, as text lines "name kernel ms gflop\n" written into buf (truncated to cap). Clears the records. */
+int lumina_ocr_conv_timing_detail(lumina_ocr_t* h, char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

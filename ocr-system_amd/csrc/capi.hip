@@ -6,6 +6,7 @@
 #include "dbpost.h"
 #include "engine.h"
 #include "ops.h"
+#include "resize.h"
 #include "stem_conv.h"
 
 #define API_TRY try {
@@ -39,6 +40,7 @@ void lumina_ocr_destroy(lumina_ocr_t* h) {
     if (!h) return;
     for (void* p : h->owned) (void)hipFree(p);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->aux) (void)hipFree(h->aux);
     for (auto& ev : h->conv_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete h;
 }
@@ -179,7 +181,100 @@ int lumina_ocr_conv_timing(lumina_ocr_t* h, double* total_ms, double* total_flop
         (void)hipEventDestroy(h->conv_events[i].first); (void)hipEventDestroy(h->conv_events[i].second);
     }
     *total_ms = ms; *total_flops = fl; *launches = (int)h->conv_events.size();
-    h->conv_events.clear(); h->conv_flops.clear(); h->conv_names.clear();
+    h->conv_events.clear(); h->conv_flops.clear(); h->conv_names.clear(); h->conv_kernels.clear();
+    return 0;
+}
+
+static int get_coeffs(lumina_ocr* h, int in_size, int out_size, lumina_ocr::Coeffs* out) {
+    auto key = std::make_pair(in_size, out_size);
+    auto it = h->coeff_cache.find(key);
+    if (it == h->coeff_cache.end()) {
+        std::vector<int> bounds, kk;
+        lumina_ocr::Coeffs c;
+        lanczos_coeffs(in_size, out_size, &c.ksize, &bounds, &kk);
+        if (hipMalloc(reinterpret_cast<void**>(&c.bounds), bounds.size() * 4) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&c.kk), kk.size() * 4) != hipSuccess)
+            return locr_fail(h, "resize", "hipMalloc coefficient tables");
+        (void)hipMemcpy(c.bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(c.kk, kk.data(), kk.size() * 4, hipMemcpyHostToDevice);
+        h->owned.push_back(c.bounds); h->owned.push_back(c.kk);
+        it = h->coeff_cache.emplace(key, c).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+/* image_preprocessing.py:81-110 on the device: two-pass 8-bit LANCZOS, byte-exact with PIL. */
+int lumina_ocr_resize_lanczos(lumina_ocr_t* h, const uint8_t* in_dev, int n, int height, int width, int channels, uint8_t* out_dev,
+                              int out_h, int out_w, void* stream) {
+    if (!h || !in_dev || !out_dev || n <= 0 || height <= 0 || width <= 0 || out_h <= 0 || out_w <= 0 || channels <= 0)
+        return locr_fail(h, "resize_lanczos", "bad arguments");
+    API_TRY
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t* src = in_dev;
+    int cur_w = width;
+    const bool need_h = out_w != width, need_v = out_h != height;
+    if (!need_h && !need_v) {
+        hipError_t e = hipMemcpyAsync(out_dev, in_dev, (size_t)n * height * width * channels, hipMemcpyDeviceToDevice, st);
+        return e == hipSuccess ? 0 : locr_fail(h, "resize_lanczos", hipGetErrorString(e));
+    }
+    if (need_h) {
+        lumina_ocr::Coeffs c;
+        if (get_coeffs(h, width, out_w, &c)) return 1;
+        uint8_t* dst = out_dev;
+        if (need_v) {
+            const size_t need = (size_t)n * height * out_w * channels;
+            if (need > h->aux_cap) {
+                if (hipDeviceSynchronize() != hipSuccess) return locr_fail(h, "resize_lanczos", "sync");
+                if (h->aux) (void)hipFree(h->aux);
+                h->aux = nullptr; h->aux_cap = 0;
+                if (hipMalloc(reinterpret_cast<void**>(&h->aux), need) != hipSuccess) return locr_fail(h, "resize_lanczos", "hipMalloc");
+                h->aux_cap = need;
+            }
+            dst = h->aux;
+        }
+        hipError_t e = resample_launch(src, dst, c.bounds, c.kk, c.ksize, n, height, width, channels, out_w, 0, st);
+        if (e != hipSuccess) return locr_fail(h, "resize_lanczos", hipGetErrorString(e));
+        src = dst; cur_w = out_w;
+    }
+    if (need_v) {
+        lumina_ocr::Coeffs c;
+        if (get_coeffs(h, height, out_h, &c)) return 1;
+        hipError_t e = resample_launch(src, out_dev, c.bounds, c.kk, c.ksize, n, height, cur_w, channels, out_h, 1, st);
+        if (e != hipSuccess) return locr_fail(h, "resize_lanczos", hipGetErrorString(e));
+    }
+    return 0;
+    API_CATCH(h)
+}
+
+/* image_preprocessing.py:132-158 (ImageEnhance.Contrast then .Sharpness) on RGB u8 [n,H,W,3]; tmp_dev: scratch, same size. */
+int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, float contrast, float sharpness,
+                       uint8_t* tmp_dev, uint8_t* out_dev, void* stream) {
+    if (!h || !img_dev || !tmp_dev || !out_dev || n <= 0) return locr_fail(h, "enhance", "bad arguments");
+    if (n > h->sums_cap) {
+        unsigned long long* s = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&s), sizeof(unsigned long long) * (size_t)n) != hipSuccess) return locr_fail(h, "enhance", "hipMalloc");
+        h->owned.push_back(s);
+        h->sums = s; h->sums_cap = n;
+    }
+    hipError_t e = enhance_launch(img_dev, tmp_dev, out_dev, h->sums, n, height, width, contrast, sharpness, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : locr_fail(h, "enhance", hipGetErrorString(e));
+}
+
+int lumina_ocr_conv_timing_detail(lumina_ocr_t* h, char* buf, size_t cap) {
+    if (!h || !buf || cap == 0) return 1;
+    if (hipDeviceSynchronize() != hipSuccess) return locr_fail(h, "conv_timing_detail", "sync failed");
+    std::string out;
+    for (size_t i = 0; i < h->conv_events.size(); ++i) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, h->conv_events[i].first, h->conv_events[i].second);
+        char line[256];
+        snprintf(line, sizeof(line), "%s %s %.4f %.4f\n", h->conv_names[i].c_str(), h->conv_kernels[i].c_str(), t, h->conv_flops[i] * 1e-9);
+        out += line;
+        (void)hipEventDestroy(h->conv_events[i].first); (void)hipEventDestroy(h->conv_events[i].second);
+    }
+    h->conv_events.clear(); h->conv_flops.clear(); h->conv_names.clear(); h->conv_kernels.clear();
+    snprintf(buf, cap, "%s", out.c_str());
     return 0;
 }
 

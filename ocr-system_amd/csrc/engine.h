@@ -62,7 +62,12 @@ struct lumina_ocr {
     bool time_convs = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_events;
     std::vector<double> conv_flops;
-    std::vector<std::string> conv_names;
+    std::vector<std::string> conv_names, conv_kernels;
+    // ---- pre-processing (resize / enhance) ----
+    struct Coeffs { int ksize = 0; int* bounds = nullptr; int* kk = nullptr; };
+    std::map<std::pair<int, int>, Coeffs> coeff_cache;  // (in, out) -> device tables
+    uint8_t* aux = nullptr; size_t aux_cap = 0;         // resize intermediate
+    unsigned long long* sums = nullptr; int sums_cap = 0;
 };
 
 int locr_fail(lumina_ocr* eng, const char* what, const char* detail);

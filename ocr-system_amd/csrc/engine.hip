@@ -209,6 +209,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         const double px = flat ? (double)p.pix_limit : (double)p.N * p.Ho * p.Wo;
         eng->conv_flops.push_back(2.0 * px * L.ks * L.ks * L.cin * L.cout);
         eng->conv_names.push_back(L.name);
+        eng->conv_kernels.push_back(conv_kernel_name(L.cfg));
     }
     return 0;
 }

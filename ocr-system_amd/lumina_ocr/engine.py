@@ -62,8 +62,9 @@ def load_library() -> ctypes.CDLL:
         "lumina_ocr_conv2d": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "lumina_ocr_read_tap": (i32, [vp, c.c_char_p, vp, sz, c.POINTER(i32)]),
         "lumina_ocr_conv_timing": (i32, [vp, c.POINTER(c.c_double), c.POINTER(c.c_double), c.POINTER(i32)]),
+        "lumina_ocr_conv_timing_detail": (i32, [vp, c.c_char_p, sz]),
         "lumina_ocr_resize_lanczos": (i32, [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
-        "lumina_ocr_enhance": (i32, [vp, vp, i32, i32, i32, f32, f32, vp, vp]),
+        "lumina_ocr_enhance": (i32, [vp, vp, i32, i32, i32, f32, f32, vp, vp, vp]),
     }
     missing = []
     for name, (res, args) in sig.items():
@@ -83,7 +84,7 @@ EXPORTED_SYMBOLS = [
     "lumina_ocr_create", "lumina_ocr_destroy", "lumina_ocr_last_error", "lumina_ocr_version", "lumina_ocr_set_option",
     "lumina_ocr_load_det_weights", "lumina_ocr_load_rec_weights", "lumina_ocr_num_classes", "lumina_ocr_normalize",
     "lumina_ocr_det_forward", "lumina_ocr_det_postprocess", "lumina_ocr_rec_crop", "lumina_ocr_rec_forward",
-    "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing",
+    "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing", "lumina_ocr_conv_timing_detail",
     "lumina_ocr_resize_lanczos", "lumina_ocr_enhance",
 ]
 
@@ -248,6 +249,15 @@ class Engine:
         self._chk(self.lib.lumina_ocr_conv_timing(self._h, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)))
         return ms.value, fl.value, n.value
 
+    def conv_timing_detail(self):
+        buf = ctypes.create_string_buffer(1 << 20)
+        self._chk(self.lib.lumina_ocr_conv_timing_detail(self._h, buf, len(buf)))
+        rows = []
+        for line in buf.value.decode().splitlines():
+            name, kern, ms, gf = line.split()
+            rows.append((name, kern, float(ms), float(gf)))
+        return rows
+
     # -- pre-processing on device (image_preprocessing.py:81-110, :132-158) -----------------
     def resize_lanczos(self, img, out_h: int, out_w: int):
         torch = _torch()
@@ -261,5 +271,5 @@ class Engine:
         n, h, w, c = img.shape
         out = torch.empty_like(img)
         tmp = torch.empty_like(img)
-        self._chk(self.lib.lumina_ocr_enhance(self._h, _ptr(img), n, h, w, contrast, sharpness, _ptr(tmp), _ptr(out)))
+        self._chk(self.lib.lumina_ocr_enhance(self._h, _ptr(img), n, h, w, contrast, sharpness, _ptr(tmp), _ptr(out), self._stream()))
         return out

@@ -1,0 +1,81 @@
+"""Batched device pipeline: pages -> (resize/enhance) -> DBNet -> DB post-process -> crops -> CRNN -> CTC.
+
+This is the arithmetic that fills the reference's engine slot
+(/root/reference/backend/services/ocr_service.py:420 `_analyze_with_azure`, :428 `_extract_layout_boxes`);
+every stage is a C-ABI call into liblumina_ocr.so.  torch is used for buffers, the stream and two tiny
+index-gather ops between stages; one host sync (box counts) separates det from rec.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import arch
+from .engine import MAX_BOXES, Engine
+from .utils.image_preprocessing import get_optimal_size
+
+
+@dataclass
+class PageDetections:
+    quads: np.ndarray          # int32 [n, 8]  TL,TR,BR,BL in processed-image pixels
+    texts: List[str]
+    scores: np.ndarray         # float32 [n]  CTC mean max-prob
+    det_scores: np.ndarray     # float32 [n]  DB box score
+    width: int = 0             # processed image size
+    height: int = 0
+
+    def triples(self) -> List[Tuple[Sequence[int], str, float]]:
+        return [(self.quads[i].tolist(), self.texts[i], float(self.scores[i])) for i in range(len(self.texts))]
+
+
+class OcrPipeline:
+    def __init__(self, engine: Engine, charset: Optional[List[str]] = None, max_dimension: int = 2000):
+        self.eng = engine
+        self.charset = charset or arch.ctc_charset(engine.num_classes or 6625)
+        self.max_dimension = max_dimension
+
+    # ---- stages -------------------------------------------------------------------------
+    def preprocess(self, pages, enhance: bool = True):
+        """uint8 [B,H,W,3] device -> processed uint8 [B,H',W',3] (image_preprocessing.py:559-628 without deskew/JPEG)."""
+        b, h, w, _ = pages.shape
+        nw, nh = get_optimal_size(w, h, self.max_dimension)
+        x = pages if (nw, nh) == (w, h) else self.eng.resize_lanczos(pages, nh, nw)
+        return self.eng.enhance(x, 1.2, 1.1) if enhance else x
+
+    def detect(self, processed):
+        b, h, w, _ = processed.shape
+        prob = self.eng.det_forward(processed)
+        return self.eng.det_postprocess(prob, h, w)
+
+    def recognize(self, processed, boxes, scores, counts) -> List[PageDetections]:
+        import torch
+        b, h, w, _ = processed.shape
+        counts_h = counts.cpu().numpy()  # the one host sync of the pipeline
+        n = int(counts_h.sum())
+        if n == 0:
+            return [PageDetections(np.zeros((0, 8), np.int32), [], np.zeros(0, np.float32), np.zeros(0, np.float32), w, h) for _ in range(b)]
+        mask = torch.arange(boxes.shape[1], device=boxes.device)[None, :] < counts[:, None]
+        quads = boxes[mask].contiguous()
+        page_idx = torch.arange(b, device=boxes.device, dtype=torch.int32)[:, None].expand(b, boxes.shape[1])[mask].contiguous()
+        det_sc = scores[mask]
+        crops, widths = self.eng.rec_crop(processed, quads, page_idx)
+        idx, prob = self.eng.rec_forward(crops, widths)
+        text, length, score = self.eng.ctc_decode(idx, prob)
+        text_h, len_h, score_h = text.cpu().numpy(), length.cpu().numpy(), score.cpu().numpy()
+        quads_h, det_h = quads.cpu().numpy(), det_sc.cpu().numpy()
+        cs = self.charset
+        out, off = [], 0
+        for p in range(b):
+            c = int(counts_h[p])
+            texts = ["".join(cs[k] for k in text_h[i, : len_h[i]]) for i in range(off, off + c)]
+            out.append(PageDetections(quads_h[off:off + c], texts, score_h[off:off + c], det_h[off:off + c], w, h))
+            off += c
+        return out
+
+    def run(self, pages, enhance: bool = True) -> Tuple[List[PageDetections], "object"]:
+        """-> (per-page detections, processed pages on device)."""
+        processed = self.preprocess(pages, enhance)
+        boxes, scores, counts = self.detect(processed)
+        return self.recognize(processed, boxes, scores, counts), processed

@@ -1,0 +1,302 @@
+"""OCR provider backed by the MI355X det+rec engine — a drop-in for the reference's provider module.
+
+Replace /root/reference/backend/services/ocr_service.py with this module: callers do
+`from services.ocr_service import OCRService, DocumentOCRResult` and `OCRService()`
+(/root/reference/backend/services/extraction_service.py:46, :207).  Mirrored surface (reference file:line):
+  OCROutput :48-79, DocumentOCRResult :82-104 (same fields, same to_dict keys; processed_image_bytes excluded)
+  OCRService: singleton :126-135, process_image_sync :477-502, _process_single_image_sync :398-475,
+    process_pdf_sync :508-602, process_pdf_as_images_sync :604-660, process_image/process_pdf (async) :666-693,
+    process_document :695-731, get_status :759-771, preload_model :773-775, is_model_loaded :777-780, cleanup :782-795
+  module level: ocr_service :802, ocr_node :805-829, preload_ocr_model :832-837, get_ocr_status :840-842
+Errors are data, never exceptions (:464-475, :653-660).  Box coordinates, page_width_inches/page_height_inches
+and processed_image_bytes (JPEG) all refer to the processed image's pixel grid.
+There is no CPU fallback: without the HIP library / a GPU every call returns success=False with the reason.
+"""
+from __future__ import annotations
+
+import asyncio
+import io
+import logging
+import os
+import threading
+import time
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Union
+
+import numpy as np
+from PIL import Image
+
+from .. import arch
+from ..utils import layout
+from ..utils.image_preprocessing import ImagePreprocessor, get_optimal_size
+
+logger = logging.getLogger(__name__)
+
+SUPPORTED_IMAGE_TYPES = ("png", "jpg", "jpeg", "webp", "bmp", "tiff")
+
+
+@dataclass
+class OCROutput:
+    markdown: str = ""
+    html: str = ""
+    json_output: Dict[str, Any] = field(default_factory=dict)
+    processing_time_ms: int = 0
+    success: bool = True
+    error: Optional[str] = None
+    page_number: int = 1
+    image_width: int = 0
+    image_height: int = 0
+    layout_boxes: List[Dict[str, Any]] = field(default_factory=list)
+    processed_image_bytes: Optional[bytes] = None
+    page_width_inches: float = 0.0
+    page_height_inches: float = 0.0
+
+    def to_dict(self) -> Dict[str, Any]:
+        keys = ("markdown", "html", "json_output", "processing_time_ms", "success", "error", "page_number", "image_width",
+                "image_height", "layout_boxes", "page_width_inches", "page_height_inches")
+        return {k: getattr(self, k) for k in keys}
+
+
+@dataclass
+class DocumentOCRResult:
+    pages: List[OCROutput] = field(default_factory=list)
+    total_pages: int = 0
+    total_processing_time_ms: int = 0
+    success: bool = True
+    error: Optional[str] = None
+    combined_markdown: str = ""
+    combined_html: str = ""
+    combined_layout_boxes: List[Dict[str, Any]] = field(default_factory=list)
+
+    def to_dict(self) -> Dict[str, Any]:
+        d = {k: getattr(self, k) for k in ("total_pages", "total_processing_time_ms", "success", "error", "combined_markdown",
+                                           "combined_html", "combined_layout_boxes")}
+        return {"pages": [p.to_dict() for p in self.pages], **d}
+
+
+def _ms_since(t0: float) -> int:
+    return int((time.time() - t0) * 1000)
+
+
+class OCRService:
+    """Process-wide singleton; pages are serialised by a semaphore exactly like the reference (:157, :404)."""
+
+    _instance = None
+    _lock = threading.Lock()
+
+    def __new__(cls):
+        if cls._instance is None:
+            with cls._lock:
+                if cls._instance is None:
+                    cls._instance = super().__new__(cls)
+                    cls._instance._initialized = False
+        return cls._instance
+
+    def __init__(self):
+        if getattr(self, "_initialized", False):
+            return
+        self._engine = None
+        self._pipeline = None
+        self._engine_lock = threading.Lock()
+        self._semaphore = threading.Semaphore(1)
+        self.max_dimension = int(os.environ.get("OCR_MAX_IMAGE_DIMENSION", 2000))
+        self._device = int(os.environ.get("LUMINA_OCR_DEVICE", os.environ.get("LOCAL_RANK", 0)))
+        self._det_weights = os.environ.get("LUMINA_OCR_DET_WEIGHTS", "")
+        self._rec_weights = os.environ.get("LUMINA_OCR_REC_WEIGHTS", "")
+        self._weights_kind = "unloaded"
+        self._pre = ImagePreprocessor(self.max_dimension)
+        self._initialized = True
+
+    # ---- engine management (reference: _ensure_client_initialized :166-207) ----
+    def _ensure_engine(self) -> None:
+        if self._pipeline is not None:
+            return
+        with self._engine_lock:
+            if self._pipeline is not None:
+                return
+            from ..engine import Engine
+            from ..pipeline import OcrPipeline
+            eng = Engine(self._device)  # raises EngineUnavailable without the HIP library / a GPU
+            if self._det_weights and self._rec_weights:
+                eng.load_det(Path(self._det_weights).read_bytes())
+                eng.load_rec(Path(self._rec_weights).read_bytes())
+                self._weights_kind = "files"
+            else:  # no trained weights ship offline: deterministic seeded networks
+                eng.load_det(arch.make_det_weights())
+                eng.load_rec(arch.make_rec_weights())
+                self._weights_kind = "seeded-synthetic"
+            self._engine = eng
+            self._pre._engine = eng
+            self._pipeline = OcrPipeline(eng, max_dimension=self.max_dimension)
+
+    # ---- single image (:398-475) ----
+    def _prepare(self, image: Image.Image) -> np.ndarray:
+        image = self._pre.auto_orient(image)
+        if image.mode != "RGB":
+            image = image.convert("RGB")
+        w, h = image.size
+        nw, nh = get_optimal_size(w, h, self.max_dimension)
+        if nw <= 0 or nh <= 0:
+            raise ValueError("height and width must be > 0")
+        return np.ascontiguousarray(np.asarray(image, np.uint8))
+
+    def _finish_page(self, det, processed_hwc: np.ndarray, page_number: int, original_size, t0: float) -> OCROutput:
+        merged, ordered = layout.reading_order(det.triples())
+        md = layout.page_markdown(merged)
+        boxes = layout.build_layout_boxes(ordered, page_number)
+        jpeg = self._pre.compress_for_azure(Image.fromarray(processed_hwc))
+        ph, pw = processed_hwc.shape[:2]
+        return OCROutput(markdown=md, html=layout.html_from_markdown(md),
+                         json_output={"page_count": 1, "words_count": sum(1 for b in boxes if b["type"] == "word"),
+                                      "lines_count": len(ordered), "tables_count": 0, "paragraphs_count": 0},
+                         processing_time_ms=_ms_since(t0), success=True, page_number=page_number, image_width=original_size[0],
+                         image_height=original_size[1], layout_boxes=boxes, processed_image_bytes=jpeg,
+                         page_width_inches=float(pw), page_height_inches=float(ph))
+
+    def _process_single_image_sync(self, image: Image.Image, page_number: int = 1) -> OCROutput:
+        with self._semaphore:
+            t0 = time.time()
+            original_size = image.size
+            try:
+                import torch
+                self._ensure_engine()
+                arr = self._prepare(image)
+                dets, processed = self._pipeline.run(torch.from_numpy(arr)[None].cuda())
+                return self._finish_page(dets[0], processed[0].cpu().numpy(), page_number, original_size, t0)
+            except Exception as e:  # errors are data (:464-475)
+                logger.error("OCR failed: %s", e)
+                return OCROutput(success=False, error=str(e), processing_time_ms=_ms_since(t0), page_number=page_number,
+                                 image_width=original_size[0], image_height=original_size[1])
+
+    def process_image_sync(self, image_source: Union[str, Path, Image.Image, bytes], page_number: int = 1) -> OCROutput:
+        if isinstance(image_source, bytes):
+            image = self._pre.load_image_bytes(image_source)
+        elif isinstance(image_source, (str, Path)):
+            image = self._pre.load_image(image_source)
+        elif isinstance(image_source, Image.Image):
+            image = image_source
+        else:
+            raise ValueError(f"Unsupported image type: {type(image_source)}")
+        return self._process_single_image_sync(image, page_number)
+
+    # ---- page batches: the data-parallel unit (reference loops pages serially, :620-627) ----
+    def process_pages_sync(self, images: List[Image.Image], first_page_number: int = 1) -> List[OCROutput]:
+        """Same-size pages go through the engine as one batch; results are identical to the per-page path."""
+        out: List[Optional[OCROutput]] = [None] * len(images)
+        with self._semaphore:
+            groups: Dict[Any, List[int]] = {}
+            for i, im in enumerate(images):
+                groups.setdefault(im.size, []).append(i)
+            for size, idxs in groups.items():
+                t0 = time.time()
+                try:
+                    import torch
+                    self._ensure_engine()
+                    batch = np.stack([self._prepare(images[i]) for i in idxs])
+                    dets, processed = self._pipeline.run(torch.from_numpy(batch).cuda())
+                    proc_h = processed.cpu().numpy()
+                    for j, i in enumerate(idxs):
+                        out[i] = self._finish_page(dets[j], proc_h[j], first_page_number + i, images[i].size, t0)
+                except Exception as e:
+                    for i in idxs:
+                        out[i] = OCROutput(success=False, error=str(e), processing_time_ms=_ms_since(t0),
+                                           page_number=first_page_number + i, image_width=images[i].size[0], image_height=images[i].size[1])
+        return out  # type: ignore[return-value]
+
+    def _document_from_pages(self, pages: List[OCROutput], t0: float) -> DocumentOCRResult:
+        ok = all(p.success for p in pages)
+        boxes: List[Dict[str, Any]] = []
+        for p in pages:
+            boxes.extend(p.layout_boxes)
+        return DocumentOCRResult(pages=pages, total_pages=len(pages), total_processing_time_ms=_ms_since(t0), success=ok,
+                                 error=None if ok else "Some pages failed", combined_markdown=layout.combine_markdown(pages),
+                                 combined_html=layout.combine_html(pages), combined_layout_boxes=boxes)
+
+    # ---- PDF (:508-660): every PDF goes through the rasterise-and-batch path ----
+    def process_pdf_as_images_sync(self, pdf_path: Union[str, Path]) -> DocumentOCRResult:
+        t0 = time.time()
+        try:
+            images = self._pre.pdf_to_images(pdf_path)
+            if not images:
+                return DocumentOCRResult(success=False, error="No pages found in PDF")
+            return self._document_from_pages(self.process_pages_sync(images), t0)
+        except Exception as e:
+            return DocumentOCRResult(success=False, error=str(e), total_processing_time_ms=_ms_since(t0))
+
+    def process_pdf_sync(self, pdf_path: Union[str, Path]) -> DocumentOCRResult:
+        if not Path(pdf_path).exists():
+            return DocumentOCRResult(success=False, error=f"File not found: {Path(pdf_path)}")
+        return self.process_pdf_as_images_sync(pdf_path)
+
+    # ---- async wrappers (:666-731) ----
+    async def process_image(self, image_source, page_number: int = 1, timeout: float = 120.0) -> OCROutput:
+        try:
+            return await asyncio.wait_for(asyncio.to_thread(self.process_image_sync, image_source, page_number), timeout=timeout)
+        except asyncio.TimeoutError:
+            return OCROutput(success=False, error=f"Timed out after {timeout}s")
+
+    async def process_pdf(self, pdf_path, timeout: float = 600.0) -> DocumentOCRResult:
+        try:
+            return await asyncio.wait_for(asyncio.to_thread(self.process_pdf_sync, pdf_path), timeout=timeout)
+        except asyncio.TimeoutError:
+            return DocumentOCRResult(success=False, error=f"Timed out after {timeout}s")
+
+    async def process_document(self, file_path: Union[str, Path], file_type: str) -> DocumentOCRResult:
+        file_type = file_type.lower().strip(".")
+        path = Path(file_path)
+        if not path.exists():
+            return DocumentOCRResult(success=False, error=f"File not found: {path}")
+        if file_type == "pdf":
+            return await self.process_pdf(path)
+        if file_type in SUPPORTED_IMAGE_TYPES:
+            r = await self.process_image(path)
+            return DocumentOCRResult(pages=[r], total_pages=1, total_processing_time_ms=r.processing_time_ms, success=r.success,
+                                     error=r.error, combined_markdown=r.markdown, combined_html=r.html, combined_layout_boxes=r.layout_boxes)
+        return DocumentOCRResult(success=False, error=f"Unsupported file type: {file_type}")
+
+    # ---- status (:759-795) ----
+    def get_status(self) -> Dict[str, Any]:
+        st = {"client_initialized": self._pipeline is not None, "model_id": "dbnet-r18vd+crnn-mv3", "max_dimension": self.max_dimension,
+              "device": self._device, "weights": self._weights_kind, "engine": "Lumina MI355X det+rec (HIP, gfx950)"}
+        if self._engine is not None:
+            st["engine_version"] = self._engine.version()
+            st["num_classes"] = self._engine.num_classes
+        return st
+
+    def preload_model(self) -> None:
+        self._ensure_engine()
+
+    @property
+    def is_model_loaded(self) -> bool:
+        return self._pipeline is not None
+
+    def cleanup(self) -> None:
+        with self._engine_lock:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = self._pipeline = None
+
+
+ocr_service = OCRService()
+
+
+async def ocr_node(state: Dict[str, Any]) -> Dict[str, Any]:
+    """LangGraph node (:805-829)."""
+    path = state.get("document_path")
+    if not path:
+        return {**state, "ocr_result": None, "ocr_markdown": "", "ocr_success": False, "ocr_error": "No document_path in state", "ocr_time_ms": 0}
+    r = await ocr_service.process_document(path, state.get("file_type", ""))
+    return {**state, "ocr_result": r.to_dict(), "ocr_markdown": r.combined_markdown, "ocr_success": r.success, "ocr_error": r.error,
+            "ocr_time_ms": r.total_processing_time_ms}
+
+
+def preload_ocr_model() -> None:
+    try:
+        ocr_service.preload_model()
+    except Exception as e:
+        logger.warning("OCR preload failed: %s", e)
+
+
+async def get_ocr_status() -> Dict[str, Any]:
+    return ocr_service.get_status()

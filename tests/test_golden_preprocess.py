@@ -1,0 +1,47 @@
+"""CPU: the oracle's restatement of the reference pre-processing vs vectors produced by the reference module itself
+(tools/make_golden.py imported /root/reference/backend/utils/image_preprocessing.py)."""
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import preprocess as P
+from lumina_ocr import synth
+from lumina_ocr.utils.image_preprocessing import ImagePreprocessor, get_optimal_size
+
+G = Path(__file__).parent / "golden"
+
+
+def test_size_table_matches_reference():
+    for w, h, ow, oh, err in json.loads((G / "resize_sizes.json").read_text()):
+        assert P.target_size(w, h) == (ow, oh)
+        assert get_optimal_size(w, h) == (ow, oh)                      # product host mirror
+        assert ImagePreprocessor().get_optimal_size(w, h) == (ow, oh)
+        if err:  # degenerate target: the reference raises ValueError inside PIL
+            assert ow == 0 or oh == 0
+
+
+@pytest.mark.parametrize("i", range(7))
+def test_pixel_vectors(i):
+    v = np.load(G / "preprocess_vectors.npz")
+    x = v[f"in{i}"]
+    assert np.array_equal(P.resize_if_needed(x, 120), v[f"resize{i}"])
+    assert np.array_equal(P.enhance_contrast(x, 1.2), v[f"contrast{i}"])
+    assert np.array_equal(P.enhance_sharpness(x, 1.1), v[f"sharp{i}"])
+    assert np.array_equal(P.optimize_for_ocr(x, 120), v[f"optimize{i}"])
+
+
+def test_a4_200dpi_page_hashes():
+    """BASELINE's page shape: 1654x2339 -> 1414x2000 (int truncation), pinned by SHA-256 of the reference's output."""
+    a4 = json.loads((G / "a4_page.json").read_text())
+    page = synth.synth_page(2339, 1654, 2024)[0]
+    assert list(page.shape) == a4["in_shape"] and hashlib.sha256(page.tobytes()).hexdigest() == a4["in_sha256"]
+    res = P.resize_if_needed(page)
+    assert list(res.shape) == a4["out_shape"] == [2000, 1414, 3]
+    y, x = a4["crop_origin"]
+    assert np.array_equal(res[y:y + 64, x:x + 64], np.array(a4["resize_crop"], np.uint8))
+    assert hashlib.sha256(res.tobytes()).hexdigest() == a4["resize_sha256"]
+    opt = P.enhance_sharpness(P.enhance_contrast(res, 1.2), 1.1)
+    assert hashlib.sha256(opt.tobytes()).hexdigest() == a4["optimize_sha256"]

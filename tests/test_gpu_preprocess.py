@@ -1,0 +1,63 @@
+"""GPU parity (bit-exact, byte work): LANCZOS resize / contrast / sharpness kernels vs the reference's own outputs
+(tests/golden/, produced by /root/reference/backend/utils/image_preprocessing.py) and vs the oracle restatement."""
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from lumina_ocr import synth
+from lumina_ocr.utils.image_preprocessing import ImagePreprocessor
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).parent / "golden"
+
+
+def _dev(x):
+    x = x if x.ndim == 3 else x[..., None]
+    return torch.from_numpy(np.ascontiguousarray(x))[None].cuda()
+
+
+@pytest.mark.parametrize("i", range(7))
+def test_golden_vectors_bit_exact(engine, i):
+    v = np.load(G / "preprocess_vectors.npz")
+    x = v[f"in{i}"]
+    pre = ImagePreprocessor(max_dimension=120, engine=engine)
+    r = pre.resize_if_needed(_dev(x))[0].cpu().numpy()
+    ref = v[f"resize{i}"]
+    assert np.array_equal(r if x.ndim == 3 else r[..., 0], ref)
+    if x.ndim == 3:
+        assert np.array_equal(engine.enhance(_dev(x), 1.2, 1.0)[0].cpu().numpy(), v[f"contrast{i}"])
+        assert np.array_equal(engine.enhance(_dev(x), 1.0, 1.1)[0].cpu().numpy(), v[f"sharp{i}"])
+        assert np.array_equal(pre.optimize_for_ocr(_dev(x))[0].cpu().numpy(), v[f"optimize{i}"])
+
+
+def test_a4_page_matches_reference_hashes(engine):
+    a4 = json.loads((G / "a4_page.json").read_text())
+    page = synth.synth_page(2339, 1654, 2024)[0]
+    assert hashlib.sha256(page.tobytes()).hexdigest() == a4["in_sha256"]
+    pre = ImagePreprocessor(engine=engine)
+    res = pre.resize_if_needed(_dev(page))
+    assert list(res.shape[1:]) == [2000, 1414, 3]
+    assert hashlib.sha256(res[0].cpu().numpy().tobytes()).hexdigest() == a4["resize_sha256"]
+    opt = engine.enhance(res, 1.2, 1.1)
+    assert hashlib.sha256(opt[0].cpu().numpy().tobytes()).hexdigest() == a4["optimize_sha256"]
+
+
+def test_batch_and_edge_sizes_vs_oracle(engine):
+    from oracle import preprocess as P
+    rng = np.random.default_rng(9)
+    x = rng.integers(0, 256, (3, 90, 260, 3), dtype=np.uint8)
+    got = engine.resize_lanczos(torch.from_numpy(x).cuda(), 69, 200).cpu().numpy()      # batch of 3, downscale
+    for k in range(3):
+        assert np.array_equal(got[k], P.resize_lanczos(x[k], 200, 69))
+    up = engine.resize_lanczos(torch.from_numpy(x[:1]).cuda(), 180, 300).cpu().numpy()[0]  # upscale (filterscale clamps to 1)
+    assert np.array_equal(up, P.resize_lanczos(x[0], 300, 180))
+    tiny = rng.integers(0, 256, (1, 2, 5, 3), dtype=np.uint8)                             # < 3 px: sharpen copies borders
+    assert np.array_equal(engine.enhance(torch.from_numpy(tiny).cuda(), 1.2, 1.1).cpu().numpy()[0],
+                          P.enhance_sharpness(P.enhance_contrast(tiny[0], 1.2), 1.1))
+    flat = np.full((1, 40, 40, 3), 255, np.uint8)                                          # saturated page: clipping branches
+    assert np.array_equal(engine.enhance(torch.from_numpy(flat).cuda(), 1.2, 1.1).cpu().numpy()[0],
+                          P.enhance_sharpness(P.enhance_contrast(flat[0], 1.2), 1.1))

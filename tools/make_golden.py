@@ -1,0 +1,144 @@
+"""Generate tests/golden/* by IMPORTING the reference's own modules (run in the build container only;
+/root/reference does not exist on the GPU box).  Only inputs and outputs are stored — never reference source.
+
+  backend/utils/image_preprocessing.py  (with a 1-attribute stub `config` module)
+  backend/utils/ocr_postprocessor.py
+  backend/utils/bbox_matcher.py
+  azure_debug_output.json               (the reference's captured result sample: schema fixture, copied as data)
+"""
+import hashlib
+import importlib.util
+import json
+import shutil
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+from PIL import Image
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference")
+OUT = ROOT / "tests" / "golden"
+sys.path.insert(0, str(ROOT / "ocr-system_amd"))
+from lumina_ocr import synth  # noqa: E402
+
+
+def load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    cfg = types.ModuleType("config")
+    cfg.settings = types.SimpleNamespace(OCR_MAX_IMAGE_DIMENSION=2000)
+    sys.modules["config"] = cfg
+    ip = load("ref_image_preprocessing", REF / "backend/utils/image_preprocessing.py")
+    pp = load("ref_ocr_postprocessor", REF / "backend/utils/ocr_postprocessor.py")
+    bm = load("ref_bbox_matcher", REF / "backend/utils/bbox_matcher.py")
+
+    # ---- 1. resize_if_needed size table (default max dimension 2000) ----
+    pre = ip.ImagePreprocessor()
+    sizes = [(1654, 2339), (2480, 3508), (2339, 1654), (2000, 2000), (2001, 2000), (2000, 1090), (4000, 3000), (3000, 4000),
+             (2001, 1), (1999, 2500), (800, 600), (2000, 2001), (5000, 5000), (2339, 2339), (1, 3000)]
+    table = []
+    for w, h in sizes:
+        ow, oh = pre.get_optimal_size(w, h)
+        try:
+            im = pre.resize_if_needed(Image.new("L", (w, h), 0))
+            assert im.size == (ow, oh)
+            table.append([w, h, ow, oh, None])
+        except ValueError as e:  # degenerate target (a side truncates to 0): the reference raises inside PIL
+            table.append([w, h, ow, oh, str(e)])
+    (OUT / "resize_sizes.json").write_text(json.dumps(table))
+
+    # ---- 2. pixel vectors: resize_if_needed / enhance_contrast / enhance_sharpness / optimize_for_ocr on small seeded images ----
+    rng = np.random.default_rng(20260130)
+    cases = {}
+    small = ip.ImagePreprocessor(max_dimension=120)
+    for i, (w, h, mode) in enumerate([(199, 156, "RGB"), (156, 199, "RGB"), (300, 74, "RGB"), (58, 240, "RGB"), (127, 180, "L"),
+                                      (120, 90, "RGB"), (320, 240, "RGB")]):
+        if i == 6:  # text-like content instead of noise
+            arr = synth.synth_page(240, 320, 5, n_lines=6)[0]
+        elif mode == "RGB":
+            arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        else:
+            arr = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        im = Image.fromarray(arr)
+        cases[f"in{i}"] = arr
+        cases[f"resize{i}"] = np.asarray(small.resize_if_needed(im))
+        cases[f"contrast{i}"] = np.asarray(small.enhance_contrast(im, factor=1.2))
+        cases[f"sharp{i}"] = np.asarray(small.enhance_sharpness(im, factor=1.1))
+        cases[f"optimize{i}"] = np.asarray(small.optimize_for_ocr(im))
+    np.savez_compressed(OUT / "preprocess_vectors.npz", **cases)
+
+    # ---- 3. full-size A4 @ 200 DPI page: hash + a crop (pins the 1654x2339 -> 1414x2000 case BASELINE names) ----
+    page = synth.synth_page(2339, 1654, 2024)[0]
+    res = np.asarray(pre.resize_if_needed(Image.fromarray(page)))
+    opt = np.asarray(pre.optimize_for_ocr(Image.fromarray(page)))
+    a4 = dict(in_shape=list(page.shape), in_sha256=hashlib.sha256(page.tobytes()).hexdigest(), out_shape=list(res.shape),
+              resize_sha256=hashlib.sha256(res.tobytes()).hexdigest(), optimize_sha256=hashlib.sha256(opt.tobytes()).hexdigest(),
+              crop_origin=[100, 200], resize_crop=res[100:164, 200:264].tolist())
+    (OUT / "a4_page.json").write_text(json.dumps(a4))
+
+    # ---- 4. reading order (group_into_lines / sort_and_merge_lines / process_ocr_result) ----
+    ro_cases = []
+    for seed in range(8):
+        r = np.random.default_rng(100 + seed)
+        items = []
+        n_lines = int(r.integers(1, 9))
+        y = 40.0
+        for _ in range(n_lines):
+            hgt = float(r.uniform(18, 40))
+            x = float(r.uniform(10, 80))
+            for _ in range(int(r.integers(1, 5))):
+                wdt = float(r.uniform(40, 300))
+                skew = float(r.uniform(-3, 3)) if seed % 2 else 0.0
+                jit = float(r.uniform(-0.3, 0.3)) * hgt
+                box = [[x, y + jit], [x + wdt, y + jit + skew], [x + wdt, y + jit + skew + hgt], [x, y + jit + hgt]]
+                items.append([box, synth.random_text(r, 2, 10), float(r.uniform(0.5, 1.0))])
+                x += wdt + float(r.uniform(5, 60))
+            y += hgt * float(r.uniform(1.2, 2.0))
+        order = r.permutation(len(items))
+        items = [items[i] for i in order]
+        merged = pp.process_ocr_result(items)
+        ro_cases.append(dict(items=items, lines=[dict(text=m.text, confidence=m.confidence, y_position=m.y_position,
+                                                       n_blocks=len(m.blocks)) for m in merged],
+                             formatted=pp.extract_text_ordered(items)))
+    # exact ties and an empty input
+    tie = [[[[10, 10], [50, 10], [50, 30], [10, 30]], "b", 0.9], [[[60, 10], [90, 10], [90, 30], [60, 30]], "c", 0.8],
+           [[[10, 10], [50, 10], [50, 30], [10, 30]], "a", 0.7]]
+    ro_cases.append(dict(items=tie, lines=[dict(text=m.text, confidence=m.confidence, y_position=m.y_position, n_blocks=len(m.blocks))
+                                            for m in pp.process_ocr_result(tie)], formatted=pp.extract_text_ordered(tie)))
+    ro_cases.append(dict(items=[], lines=[], formatted=pp.extract_text_ordered([])))
+    (OUT / "reading_order.json").write_text(json.dumps(ro_cases))
+
+    # ---- 5. bbox matcher on the reference's own captured sample + synthetic line boxes ----
+    sample = json.loads((REF / "azure_debug_output.json").read_text())
+    boxes = sample["combined_layout_boxes_sample"]
+    lines = [dict(type="line", content="SPRINGFIELD UNIVERSITY - UNDERGRADUATE", polygon=[383.0, 148.0, 1400.0, 176.0, 1398.0, 215.0, 381.0, 183.0], page_number=1),
+             dict(type="line", content="Applicant Name: Jordan Whitfield", polygon=[100.0, 300.0, 700.0, 300.0, 700.0, 340.0, 100.0, 340.0], page_number=1),
+             dict(type="line", content="Date of Birth", polygon=[100.0, 400.0, 400.0, 400.0, 400.0, 440.0, 100.0, 440.0], page_number=2)]
+    layout = boxes + lines
+    m = bm.BoundingBoxMatcher(layout)
+    queries = [("University", "SPRINGFIELD UNIVERSITY - UNDERGRADUATE", None), ("Applicant Name", "Jordan Whitfield", None),
+               ("springfield", "UNIVERSITY", None), ("Date of Birth", "nothing here", 2), ("Date of Birth", "x", 1),
+               ("SPRINGFIELD UNIVERSITY", "UNDERGRADUATE SPRINGFIELD", None), ("", "   ", None), ("Applicant Nmae: Jordan Whitfeld", "-", None)]
+    bm_cases = []
+    for k, v, pg in queries:
+        kb, vb = m.find_key_value_pair(k, v, pg)
+        bm_cases.append(dict(key=k, value=v, page=pg, key_bbox=kb, value_bbox=vb))
+    (OUT / "bbox_matcher.json").write_text(json.dumps(dict(layout=layout, cases=bm_cases)))
+
+    # ---- 6. schema fixture ----
+    shutil.copyfile(REF / "azure_debug_output.json", OUT / "azure_debug_output.json")
+    print("golden vectors written to", OUT)
+    for p in sorted(OUT.iterdir()):
+        print("  %-28s %8d bytes" % (p.name, p.stat().st_size))
+
+
+if __name__ == "__main__":
+    main()
