@@ -53,7 +53,8 @@ def cpu_baseline(det_w, rec_w, charset, n_pages=1):
     torch.set_num_threads(cores)
     pages = np.stack([synth.synth_page(A4_H, A4_W, 2024 + k, n_lines=60)[0] for k in range(n_pages)])
     t0 = time.time()
-    out, _ = op.run_pages(det_w, rec_w, pages, charset, mode="fp32")
+    from lumina_ocr import arch
+    out, _ = op.run_pages(det_w, rec_w, pages, charset, mode="fp32", post=arch.TEXT_PATH_POST)
     dt = time.time() - t0
     return {"value": round(n_pages / dt, 4), "unit": "pages/sec", "cores": cores, "kind": "port",
             "sample": "%d A4@200DPI page(s), full path (resize+enhance+det+post+crop+rec+ctc), oracle/ torch-CPU fp32, %d lines found, %.1f s"
@@ -92,7 +93,7 @@ def main():
     eng.load_det(det_w)
     eng.load_rec(rec_w)
     eng.set_option("det_sub_batch", args.det_sub_batch)
-    pipe = OcrPipeline(eng)
+    pipe = OcrPipeline(eng, post=arch.TEXT_PATH_POST)
     pages = make_pages(torch, args.pages, 2024 + 1000 * rank, device)
 
     def step():

@@ -200,7 +200,65 @@ def _he(rng, cout, k, cin, gain=1.0, depthwise=False):
     return bf16_round(w)
 
 
-def make_det_weights(seed: int = 1234) -> Dict[str, np.ndarray]:
+# Hand-set "text kernel" path (channel 0 of every tensor it crosses), installed on top of the seeded random
+# weights so that synthetic pages produce real line boxes (no trained checkpoint exists offline):
+#   stem.conv1 ch k<9 : relu(-mean_rgb(xn at tap k) - 0.5)            per-pixel "ink" (darker than mid-gray)
+#   stem.conv2 ch 0   : sum of the 9 ink taps                          ink in a 3x3 window
+#   stem.conv3 ch 0   : 1x3 horizontal sum / 4 ; max-pool              (1/4 resolution)
+#   s0.*              : carried unchanged (shortcut = identity on ch 0, residual branch row 0 = 0)
+#   fpn.in2/p2, head  : ch 0 -> 1x3 horizontal smoothing twice -> logit = gain * S - offset
+# Rows feeding channel 0 read nothing else; every other row stays random (dense, realistic operands).
+TEXT_GAIN, TEXT_OFFSET = 8.0, 26.0
+# Post-process parameters that go with the hand-set kernel: it spans the full glyph height and is near-binary, whereas a
+# trained DB kernel is shrunk (ratio 0.4) and soft, for which PaddleOCR's defaults (unclip 1.5, box_thresh 0.6) are meant.
+TEXT_PATH_POST = dict(unclip_ratio=0.35, box_thresh=0.5)
+DEFAULT_POST = dict(unclip_ratio=DET_UNCLIP_RATIO, box_thresh=DET_BOX_THRESH)
+
+
+def _install_text_path(w: Dict[str, np.ndarray]) -> None:
+    def zero_row(name, row=0):
+        w[name + ".w"][row] = 0.0
+        w[name + ".b"][row % len(w[name + ".b"])] = 0.0
+
+    for k in range(9):
+        zero_row("stem.conv1", k)
+        w["stem.conv1.w"][k, k // 3, k % 3, :] = -1.0 / 3.0
+        w["stem.conv1.b"][k] = -0.5
+    zero_row("stem.conv2")
+    w["stem.conv2.w"][0, 1, 1, :9] = 1.0
+    zero_row("stem.conv3")
+    w["stem.conv3.w"][0, 1, :, 0] = 0.25
+    # 1/4 resolution: four horizontal 1x3 low-pass stages inside stage 0 (long horizontal runs = text lines survive,
+    # short blobs such as descenders bridging two lines are attenuated)
+    zero_row("s0.b0.short")
+    zero_row("s0.b0.conv0", 1)
+    w["s0.b0.conv0.w"][1, 1, :, 0] = 1.0 / 3.0
+    zero_row("s0.b0.conv1")
+    w["s0.b0.conv1.w"][0, 1, :, 1] = 1.0 / 3.0
+    zero_row("s0.b1.conv0", 1)
+    w["s0.b1.conv0.w"][1, 1, :, 0] = 1.0 / 3.0
+    zero_row("s0.b1.conv1")
+    w["s0.b1.conv1.w"][0, 1, :, 1] = 1.0 / 3.0
+    for lvl in (3, 4, 5):
+        zero_row(f"fpn.in{lvl}")
+    zero_row("fpn.in2")
+    w["fpn.in2.w"][0, 0, 0, 0] = 1.0
+    zero_row("fpn.p2")
+    w["fpn.p2.w"][0, 1, :, 0] = 1.0 / 3.0
+    zero_row("head.conv1")
+    w["head.conv1.w"][0, 1, :, 192] = 1.0 / 3.0
+    for q in range(4):
+        zero_row("head.convt2", q * 64)
+        w["head.convt2.w"][q * 64, 0, 0, 0] = 1.0
+        w["head.convt3.w"][q] = 0.0
+        w["head.convt3.w"][q, 0, 0, 0] = TEXT_GAIN
+    w["head.convt3.b"][:] = -TEXT_OFFSET
+    for k in list(w):
+        if k.endswith(".w"):
+            w[k] = bf16_round(w[k])
+
+
+def make_det_weights(seed: int = 1234, text_path: bool = True) -> Dict[str, np.ndarray]:
     """name.w: OHWI float32 (bf16-exact), name.b: float32 [cout]. convT: [(dy*2+dx)*cout+co][cin]."""
     rng = np.random.default_rng(seed)
     w: Dict[str, np.ndarray] = {}
@@ -229,6 +287,8 @@ def make_det_weights(seed: int = 1234) -> Dict[str, np.ndarray]:
         if n == "head.convt3":
             b[:] = np.float32(-0.5)
         w[n + ".b"] = b.astype(np.float32)
+    if text_path:
+        _install_text_path(w)
     return w
 
 
@@ -244,13 +304,14 @@ def make_rec_weights(seed: int = 4321, num_classes: int = 6625, scale: float = 0
     conv("rec.conv1", c0, 3, 3)
     for b in rec_block_table(scale):
         p = f"rec.b{b['idx']}"
-        conv(p + ".expand", b["exp"], 1, b["cin"])
-        conv(p + ".dw", b["exp"], b["k"], b["exp"], depthwise=True)
+        hs = b["act"] == "hswish"  # hard-swish roughly halves small activations: compensate so the signal survives 11 blocks
+        conv(p + ".expand", b["exp"], 1, b["cin"], gain=1.25 if hs else 1.0)
+        conv(p + ".dw", b["exp"], b["k"], b["exp"], gain=1.25 if hs else 1.0, depthwise=True)
         if b["se"]:
             conv(p + ".se1", b["se_mid"], 1, b["exp"])
             conv(p + ".se2", b["exp"], 1, b["se_mid"], gain=0.7071)
-        conv(p + ".project", b["cout"], 1, b["exp"], gain=0.7071)
-    conv("rec.conv2", REC_FEAT, 1, rec_block_table(scale)[-1]["cout"])
+        conv(p + ".project", b["cout"], 1, b["exp"], gain=(0.5 if b["res"] else 1.4) * (1.4 if b["se"] else 1.0))
+    conv("rec.conv2", REC_FEAT, 1, rec_block_table(scale)[-1]["cout"], gain=1.0)
     h = REC_HIDDEN
     for layer, din in ((0, REC_FEAT), (1, 2 * h)):
         for d in ("fw", "bw"):
@@ -258,7 +319,7 @@ def make_rec_weights(seed: int = 4321, num_classes: int = 6625, scale: float = 0
             w[p + ".w_ih"] = bf16_round(rng.uniform(-1, 1, (4 * h, din)).astype(np.float32) * np.float32(1.0 / np.sqrt(h)))
             w[p + ".w_hh"] = bf16_round(rng.uniform(-1, 1, (4 * h, h)).astype(np.float32) * np.float32(1.0 / np.sqrt(h)))
             w[p + ".b"] = (rng.uniform(-1, 1, 4 * h).astype(np.float32) * np.float32(1.0 / np.sqrt(h))).astype(np.float32)
-    w["ctc.fc.w"] = bf16_round(rng.standard_normal((num_classes, 2 * h), dtype=np.float32) * np.float32(4.0 / np.sqrt(2 * h)))
+    w["ctc.fc.w"] = bf16_round(rng.standard_normal((num_classes, 2 * h), dtype=np.float32) * np.float32(12.0 / np.sqrt(2 * h)))
     w["ctc.fc.b"] = (rng.standard_normal(num_classes, dtype=np.float32) * np.float32(0.1)).astype(np.float32)
     return w
 

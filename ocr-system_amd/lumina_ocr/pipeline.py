@@ -31,10 +31,11 @@ class PageDetections:
 
 
 class OcrPipeline:
-    def __init__(self, engine: Engine, charset: Optional[List[str]] = None, max_dimension: int = 2000):
+    def __init__(self, engine: Engine, charset: Optional[List[str]] = None, max_dimension: int = 2000, post: Optional[dict] = None):
         self.eng = engine
         self.charset = charset or arch.ctc_charset(engine.num_classes or 6625)
         self.max_dimension = max_dimension
+        self.post = dict(arch.DEFAULT_POST if post is None else post)
 
     # ---- stages -------------------------------------------------------------------------
     def preprocess(self, pages, enhance: bool = True):
@@ -47,7 +48,7 @@ class OcrPipeline:
     def detect(self, processed):
         b, h, w, _ = processed.shape
         prob = self.eng.det_forward(processed)
-        return self.eng.det_postprocess(prob, h, w)
+        return self.eng.det_postprocess(prob, h, w, **self.post)
 
     def recognize(self, processed, boxes, scores, counts) -> List[PageDetections]:
         import torch

@@ -128,7 +128,8 @@ class OCRService:
                 self._weights_kind = "seeded-synthetic"
             self._engine = eng
             self._pre._engine = eng
-            self._pipeline = OcrPipeline(eng, max_dimension=self.max_dimension)
+            post = arch.TEXT_PATH_POST if self._weights_kind == "seeded-synthetic" else arch.DEFAULT_POST
+            self._pipeline = OcrPipeline(eng, max_dimension=self.max_dimension, post=post)
 
     # ---- single image (:398-475) ----
     def _prepare(self, image: Image.Image) -> np.ndarray:

@@ -12,7 +12,8 @@ from lumina_ocr import arch
 from . import dbpost, nets, preprocess, reading_order
 
 
-def run_pages(det_w, rec_w, pages_u8: np.ndarray, charset: List[str], enhance: bool = True, max_dim: int = 2000, mode: str = "bf16"):
+def run_pages(det_w, rec_w, pages_u8: np.ndarray, charset: List[str], enhance: bool = True, max_dim: int = 2000, mode: str = "bf16",
+              post: dict = None):
     """pages [B,H,W,3] u8 -> (list per page of dict(quads int32 [n,8], texts, scores, det_scores), processed [B,H',W',3])."""
     processed = []
     for pg in pages_u8:
@@ -26,7 +27,7 @@ def run_pages(det_w, rec_w, pages_u8: np.ndarray, charset: List[str], enhance: b
     bits = arch.f32_to_bf16_bits(prob)
     out = []
     for i in range(b):
-        quads, dsc, _ = dbpost.db_postprocess(bits[i], h, w)
+        quads, dsc, _ = dbpost.db_postprocess(bits[i], h, w, **(post or {}))
         if len(quads) == 0:
             out.append(dict(quads=quads, texts=[], scores=np.zeros(0, np.float32), det_scores=dsc))
             continue

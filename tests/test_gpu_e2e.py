@@ -27,12 +27,12 @@ def _edit(a, b):
 
 def test_pipeline_matches_oracle_pipeline(engine, det_weights, rec_weights):
     from oracle import pipeline as op
-    pages = np.stack([synth.synth_page(300, 420, 40 + i, n_lines=7)[0] for i in range(2)])
+    pages = np.stack([synth.synth_page(700, 1000, 40 + i, n_lines=14)[0] for i in range(2)])
     engine.load_det(det_weights)
     engine.load_rec(rec_weights)
-    pipe = OcrPipeline(engine, max_dimension=256)           # exercises the LANCZOS path: 420x300 -> 256x182
+    pipe = OcrPipeline(engine, max_dimension=800, post=arch.TEXT_PATH_POST)   # exercises the LANCZOS path: 1000x700 -> 800x560
     dets, processed = pipe.run(torch.from_numpy(pages).cuda())
-    ref, ref_processed = op.run_pages(det_weights, rec_weights, pages, pipe.charset, max_dim=256)
+    ref, ref_processed = op.run_pages(det_weights, rec_weights, pages, pipe.charset, max_dim=800, post=arch.TEXT_PATH_POST)
     assert np.array_equal(processed.cpu().numpy(), ref_processed)         # byte path: exact
     n_match = n_ref = n_exact_box = n_exact_text = 0
     ious, eds, nchar = [], 0, 0
