@@ -49,7 +49,8 @@ def cpu_baseline(det_w, rec_w, charset, n_pages=1):
     import torch
     from lumina_ocr import synth
     from oracle import pipeline as op
-    cores = os.cpu_count() or 1
+    # the GPU box exposes every host core but grants a share of 16 per GPU: use that share, and say so
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("LUMINA_CPU_BASELINE_THREADS", 16)))
     torch.set_num_threads(cores)
     pages = np.stack([synth.synth_page(A4_H, A4_W, 2024 + k, n_lines=60)[0] for k in range(n_pages)])
     t0 = time.time()

@@ -163,7 +163,7 @@ class OCRService:
                 import torch
                 self._ensure_engine()
                 arr = self._prepare(image)
-                dets, processed = self._pipeline.run(torch.from_numpy(arr)[None].cuda())
+                dets, processed = self._pipeline.run(torch.from_numpy(arr.copy())[None].cuda())
                 return self._finish_page(dets[0], processed[0].cpu().numpy(), page_number, original_size, t0)
             except Exception as e:  # errors are data (:464-475)
                 logger.error("OCR failed: %s", e)
