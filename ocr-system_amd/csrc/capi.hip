@@ -53,6 +53,7 @@ int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value) {
     else if (!strcmp(key, "rec_sub_batch")) h->rec_sub_batch = value > 0 ? value : 1;
     else if (!strcmp(key, "keep_taps")) h->keep_taps = value != 0;
     else if (!strcmp(key, "time_convs")) h->time_convs = value != 0;
+    else if (!strcmp(key, "fuse_head")) h->fuse_head = value != 0;
     else return locr_fail(h, "set_option: unknown key", key);
     return 0;
 }

@@ -23,6 +23,11 @@ struct ConvParams {
     int act;
     int out_mode, up_shift, convt_c;
     int tiles_x, tiles_y, n_tiles;  // spatial tiles per image, cout tiles
+    // OUT_CONVT only: fuse a following 2x2/s2 transposed conv to ONE channel + sigmoid (DBHead's last layer) into the
+    // epilogue: fuse_w [4][convt_c] bf16 (row q2 = dy2*2+dx2), fuse_b scalar; y is then the bf16 probability map
+    // [N, 4*Ho, 4*Wo] and the intermediate 64-channel tensor is never written.
+    const bf16_t* fuse_w;
+    float fuse_b;
     int pix_limit;  // flat-GEMM mode (1x1): pixels >= pix_limit of an image are neither read nor written (0 = off)
 };
 

@@ -199,6 +199,37 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(cons
         }
     }
     __syncthreads();
+    if (p.out_mode == OUT_CONVT && p.fuse_w != nullptr) {
+        // one thread per tile pixel and per 64-channel group q of this cout tile: 4 dot products -> sigmoid -> 2x2 block
+        const int tp = tid;
+        const int ty = tp / TW, tx = tp - ty * TW;
+        const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
+        if (oy < p.Ho && ox < p.Wo) {
+            const int cc = p.convt_c;  // 64
+            for (int qq = 0; qq < BN / 64; ++qq) {
+                const int q = (ntile * BN) / cc + qq;
+                float a0 = p.fuse_b, a1 = p.fuse_b, a2 = p.fuse_b, a3 = p.fuse_b;
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(stage + tp * C::STAGE_PITCH + qq * 128 + c8 * 16);
+                    const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = __uint_as_float((j & 1) ? (vv[j >> 1] & 0xFFFF0000u) : (vv[j >> 1] << 16));
+                        const int c = c8 * 8 + j;
+                        a0 = a0 + x * bf16_to_f32(p.fuse_w[0 * cc + c]);
+                        a1 = a1 + x * bf16_to_f32(p.fuse_w[1 * cc + c]);
+                        a2 = a2 + x * bf16_to_f32(p.fuse_w[2 * cc + c]);
+                        a3 = a3 + x * bf16_to_f32(p.fuse_w[3 * cc + c]);
+                    }
+                }
+                const int yy = 4 * oy + 2 * (q >> 1), xx = 4 * ox + 2 * (q & 1);
+                bf16_t* dst = p.y + ((size_t)n_img * (4 * p.Ho) + yy) * (size_t)(4 * p.Wo) + xx;
+                *reinterpret_cast<uint32_t*>(dst) = pack_bf16x2(apply_act(a0, ACT_SIGMOID), apply_act(a1, ACT_SIGMOID));
+                *reinterpret_cast<uint32_t*>(dst + 4 * p.Wo) = pack_bf16x2(apply_act(a2, ACT_SIGMOID), apply_act(a3, ACT_SIGMOID));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < C::CPP; ++k) {
         const int i = tid + 256 * k;
@@ -277,6 +308,7 @@ bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cf
     cfg->ks = ks; cfg->stride = stride; cfg->tw = 32;
     cfg->ck = (cin % 32 == 0) ? 32 : 16;
     cfg->bn = cout_gemm <= 32 ? 32 : (cout_gemm <= 64 ? 64 : 128);
+    if (ks == 1 && cfg->bn == 128) cfg->bn = 64;  // 1x1 layers are bandwidth-bound: smaller tiles, 4 workgroups per CU
     if (ks == 3 && stride == 2 && cfg->bn == 128 && cfg->ck == 32) cfg->bn = 64;  // halo tile is 4x larger: keep LDS < 160 KB
     return true;
 }

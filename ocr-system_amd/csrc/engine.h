@@ -21,6 +21,7 @@ struct ConvLayer {
     int convt_c = 0;
     ConvKernelCfg cfg{};
     bf16_t* wpk = nullptr;  // device
+    bf16_t* fuse_w = nullptr; float fuse_b = 0.f;  // optional fused DBHead tail (see ConvParams)
     float* bias = nullptr;  // device, n_tiles*BN
 };
 
@@ -58,6 +59,7 @@ struct lumina_ocr {
     int det_sub_batch = 4, rec_sub_batch = 2048;
     std::map<std::string, Tensor4> taps;  // last forward's intermediates (debug / parity tests)
     bool keep_taps = false;
+    bool fuse_head = true;  // head.convt3 fused into head.convt2's epilogue
     // per-kernel event timing (bench roofline): accumulated conv-kernel time of the last det forward
     bool time_convs = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_events;

@@ -167,6 +167,15 @@ int eng_load_det(lumina_ocr* eng, const void* blob, size_t n) {
         ConvLayer& L3 = eng->det["head.convt3"];
         if (!make_conv(eng, m, "head.convt3", 1, 1, 64, 4, 64, 4, ACT_SIGMOID, &L3, 4)) return 1;
         L3.convt = true; L3.convt_c = 1;
+        // fused tail: raw convt3 weights [4][64] + scalar bias live next to convt2
+        const HostBlobTensor *w3, *b3;
+        if (!get_wb(eng, m, "head.convt3", &w3, &b3)) return 1;
+        ConvLayer& Lf = eng->det["head.convt2.fused"];
+        Lf = L;
+        Lf.name = "head.convt2+3";
+        Lf.fuse_w = static_cast<bf16_t*>(dev_upload(eng, w3->data, 4 * 64 * sizeof(bf16_t)));
+        Lf.fuse_b = reinterpret_cast<const float*>(b3->data)[0];
+        if (!Lf.fuse_w) return locr_fail(eng, "upload", "head.convt3 fused weights");
     }
     eng->det_loaded = true;
     return 0;
@@ -179,6 +188,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     p.x = x.p; p.wpk = L.wpk; p.bias = L.bias; p.res = res ? res->p : nullptr; p.y = y->p;
     p.Cin = L.cin; p.Cout = L.cout; p.act = L.act;
     p.out_mode = out_mode; p.up_shift = up_shift; p.convt_c = L.convt_c;
+    p.fuse_w = (out_mode == OUT_CONVT) ? L.fuse_w : nullptr; p.fuse_b = L.fuse_b;
     if (flat) {  // 1x1 conv == GEMM over all pixels: re-tile as rows of 32 so every 8x32 tile is full
         const long long m = (long long)x.n * x.h * x.w;
         p.N = 1; p.W = 32; p.H = (int)((m + 31) / 32); p.pix_limit = (int)m;
@@ -283,10 +293,14 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
     tap(eng, "fpn.fuse", fuse);
     Tensor4 h1 = ws_tensor(eng, B, Hp / 4, Wp / 4, 64);
     RUN(eng_run_conv(eng, D["head.conv1"], fuse, &h1, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "head.conv1", h1);
-    Tensor4 h2 = ws_tensor(eng, B, Hp / 2, Wp / 2, 64);
-    RUN(eng_run_conv(eng, D["head.convt2"], h1, &h2, nullptr, 0, OUT_CONVT, 0, 0, 0, false, st)); tap(eng, "head.convt2", h2);
     Tensor4 pm; pm.p = prob; pm.n = B; pm.h = Hp; pm.w = Wp; pm.c = 1;
     if (dry) pm.p = nullptr;
+    if (eng->fuse_head && !eng->keep_taps) {  // DBHead tail in one launch: the 64-channel 1/2-resolution tensor never exists
+        RUN(eng_run_conv(eng, D["head.convt2.fused"], h1, &pm, nullptr, 0, OUT_CONVT, 0, 1, 0, false, st));
+        return 0;
+    }
+    Tensor4 h2 = ws_tensor(eng, B, Hp / 2, Wp / 2, 64);
+    RUN(eng_run_conv(eng, D["head.convt2"], h1, &h2, nullptr, 0, OUT_CONVT, 0, 0, 0, false, st)); tap(eng, "head.convt2", h2);
     RUN(eng_run_conv(eng, D["head.convt3"], h2, &pm, nullptr, 0, OUT_CONVT1, 0, 1, 0, false, st));
     return 0;
 }
@@ -298,9 +312,7 @@ int eng_det_forward(lumina_ocr* eng, const uint8_t* pages, int B, int H, int W, 
     const int sb = eng->det_sub_batch < B ? eng->det_sub_batch : B;
     // size the workspace with a dry run
     uint8_t* keep = eng->ws; eng->ws = nullptr;
-    const bool kt = eng->keep_taps; eng->keep_taps = false;
     int rc = det_forward_sub(eng, nullptr, sb, H, W, Hp, Wp, nullptr, st);
-    eng->keep_taps = kt;
     const size_t need = eng->ws_off + 4096;
     eng->ws = keep;
     if (rc) return rc;
@@ -504,9 +516,7 @@ int eng_rec_forward(lumina_ocr* eng, const uint8_t* crops, const int* widths, in
     HIPCHK(hipSetDevice(eng->device));
     const int sb = eng->rec_sub_batch < N ? eng->rec_sub_batch : N;
     uint8_t* keep = eng->ws; eng->ws = nullptr;
-    const bool kt = eng->keep_taps; eng->keep_taps = false;
     int rc = rec_forward_sub(eng, nullptr, nullptr, sb, nullptr, nullptr, st);
-    eng->keep_taps = kt;
     const size_t need = eng->ws_off + 4096;
     eng->ws = keep;
     if (rc) return rc;

@@ -14,35 +14,84 @@ namespace {
 
 constexpr int PRECISION_BITS = 32 - 8 - 2;
 
-__global__ void resample_kernel(const uint8_t* in, uint8_t* out, const int* bounds, const int* kk, int ksize, int N, int H, int W, int C,
-                                int outLen, int axis /*0: along W (horizontal), 1: along H (vertical)*/) {
-    const int oH = axis ? outLen : H, oW = axis ? W : outLen;
-    const size_t total = (size_t)N * oH * oW * C;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C);
-        size_t t = e / C;
-        const int xo = (int)(t % oW); t /= oW;
-        const int yo = (int)(t % oH);
-        const int n = (int)(t / oH);
-        const int o = axis ? yo : xo;
-        const int lo = bounds[2 * o], cnt = bounds[2 * o + 1];
-        const int* k = kk + (size_t)o * ksize;
-        int ss = 1 << (PRECISION_BITS - 1);
-        const uint8_t* base = in + (size_t)n * H * W * C;
-        if (axis == 0) {
-            const uint8_t* p = base + ((size_t)yo * W + lo) * C + c;
-            for (int j = 0; j < cnt; ++j) ss += (int)p[(size_t)j * C] * k[j];
-        } else {
-            const uint8_t* p = base + ((size_t)lo * W + xo) * C + c;
-            for (int j = 0; j < cnt; ++j) ss += (int)p[(size_t)j * W * C] * k[j];
+// Horizontal pass: one workgroup per input row.  The row is staged in LDS with aligned 4-byte loads, every thread then
+// produces output bytes e = xo*C + c (coalesced byte stores); coefficient rows come from L1/L2 (shared by all rows).
+__global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* in, uint8_t* out, const int* bounds, const int* kk, int ksize, int H, int W,
+                                                         int C, int Wo, size_t total_bytes) {
+    extern __shared__ uint32_t row_lds[];
+    const int row = blockIdx.x;  // n*H + y
+    const size_t start = (size_t)row * W * C;
+    const int off = (int)(start & 3);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in + (start - off));
+    const int nwords = (off + W * C + 3) >> 2;
+    const size_t wbase = start - off;
+    for (int i = threadIdx.x; i < nwords; i += 256) {
+        uint32_t w;
+        if (wbase + 4 * (size_t)(i + 1) <= total_bytes) w = src[i];
+        else {  // last word of the buffer: never read past the allocation
+            w = 0;
+            for (int b = 0; b < 4; ++b)
+                if (wbase + 4 * (size_t)i + b < total_bytes) w |= (uint32_t)in[wbase + 4 * (size_t)i + b] << (8 * b);
         }
+        row_lds[i] = w;
+    }
+    __syncthreads();
+    const uint8_t* rb = reinterpret_cast<const uint8_t*>(row_lds) + off;
+    uint8_t* orow = out + (size_t)row * Wo * C;
+    for (int e = threadIdx.x; e < Wo * C; e += 256) {
+        const int xo = e / C, c = e - xo * C;
+        const int lo = bounds[2 * xo], cnt = bounds[2 * xo + 1];
+        const int* k = kk + (size_t)xo * ksize;
+        int ss = 1 << (PRECISION_BITS - 1);
+        const uint8_t* p = rb + lo * C + c;
+        for (int j = 0; j < cnt; ++j) ss += (int)p[j * C] * k[j];
         int v = ss >> PRECISION_BITS;
-        v = v < 0 ? 0 : (v > 255 ? 255 : v);
-        out[e] = (uint8_t)v;
+        orow[e] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
     }
 }
 
-__global__ void gray_sum_kernel(const uint8_t* img, unsigned long long* sums, int HW) {
+// Vertical pass: one workgroup per output row; threads sweep the row VEC bytes at a time (coefficients are row-uniform).
+template <int VEC>
+__global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t* in, uint8_t* out, const int* bounds, const int* kk, int ksize, int H,
+                                                         int rowbytes, int Ho) {
+    const int n = blockIdx.x / Ho, yo = blockIdx.x - n * Ho;
+    const int lo = bounds[2 * yo], cnt = bounds[2 * yo + 1];
+    const int* k = kk + (size_t)yo * ksize;
+    const uint8_t* base = in + ((size_t)n * H + lo) * rowbytes;
+    uint8_t* orow = out + ((size_t)n * Ho + yo) * rowbytes;
+    for (int xb = threadIdx.x * VEC; xb < rowbytes; xb += 256 * VEC) {
+        int ss[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ss[v] = 1 << (PRECISION_BITS - 1);
+        for (int j = 0; j < cnt; ++j) {
+            const uint8_t* p = base + (size_t)j * rowbytes + xb;
+            const int kj = k[j];
+            if (VEC == 4) {
+                const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+                ss[0] += (int)(w & 0xff) * kj; ss[1 % VEC] += (int)((w >> 8) & 0xff) * kj;
+                ss[2 % VEC] += (int)((w >> 16) & 0xff) * kj; ss[3 % VEC] += (int)(w >> 24) * kj;
+            } else if (VEC == 2) {
+                const uint32_t w = *reinterpret_cast<const uint16_t*>(p);
+                ss[0] += (int)(w & 0xff) * kj; ss[1 % VEC] += (int)(w >> 8) * kj;
+            } else {
+                ss[0] += (int)p[0] * kj;
+            }
+        }
+        uint32_t packed = 0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            int q = ss[v] >> PRECISION_BITS;
+            q = q < 0 ? 0 : (q > 255 ? 255 : q);
+            packed |= (uint32_t)q << (8 * v);
+        }
+        if (VEC == 4) *reinterpret_cast<uint32_t*>(orow + xb) = packed;
+        else if (VEC == 2) *reinterpret_cast<uint16_t*>(orow + xb) = (uint16_t)packed;
+        else orow[xb] = (uint8_t)packed;
+    }
+}
+
+__global__ __launch_bounds__(256) void gray_sum_kernel(const uint8_t* img, unsigned long long* sums, int HW) {
+    __shared__ unsigned long long part[4];
     const int n = blockIdx.y;
     const uint8_t* p = img + (size_t)n * HW * 3;
     unsigned long long s = 0;
@@ -54,7 +103,9 @@ __global__ void gray_sum_kernel(const uint8_t* img, unsigned long long* sums, in
         const unsigned lo = __shfl_xor((unsigned)(s & 0xffffffffull), m), hi = __shfl_xor((unsigned)(s >> 32), m);
         s += ((unsigned long long)hi << 32) | lo;
     }
-    if ((threadIdx.x & 63) == 0) atomicAdd(&sums[n], s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sums[n], part[0] + part[1] + part[2] + part[3]);  // one atomic per workgroup
 }
 
 __device__ __forceinline__ uint8_t blend_u8(int deg, int v, float alpha) {
@@ -163,8 +214,24 @@ void lanczos_coeffs(int in_size, int out_size, int* ksize_out, std::vector<int>*
 
 hipError_t resample_launch(const uint8_t* in, uint8_t* out, const int* bounds_dev, const int* kk_dev, int ksize, int N, int H, int W, int C,
                            int out_len, int axis, hipStream_t st) {
-    const size_t total = (size_t)N * (axis ? out_len : H) * (axis ? W : out_len) * C;
-    hipLaunchKernelGGL(resample_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, out, bounds_dev, kk_dev, ksize, N, H, W, C, out_len, axis);
+    if (axis == 0) {
+        const size_t lds = ((size_t)W * C + 8 + 3) / 4 * 4;
+        if (lds > 150 * 1024) return hipErrorInvalidValue;
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resample_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        hipLaunchKernelGGL(resample_h_kernel, dim3(N * H), dim3(256), lds, st, in, out, bounds_dev, kk_dev, ksize, H, W, C, out_len, (size_t)N * H * W * C);
+    } else {
+        const int rowbytes = W * C;
+        const bool a4 = rowbytes % 4 == 0 && (reinterpret_cast<uintptr_t>(in) % 4 == 0) && (reinterpret_cast<uintptr_t>(out) % 4 == 0);
+        const bool a2 = rowbytes % 2 == 0 && (reinterpret_cast<uintptr_t>(in) % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 2 == 0);
+        if (a4) hipLaunchKernelGGL(resample_v_kernel<4>, dim3(N * out_len), dim3(256), 0, st, in, out, bounds_dev, kk_dev, ksize, H, rowbytes, out_len);
+        else if (a2) hipLaunchKernelGGL(resample_v_kernel<2>, dim3(N * out_len), dim3(256), 0, st, in, out, bounds_dev, kk_dev, ksize, H, rowbytes, out_len);
+        else hipLaunchKernelGGL(resample_v_kernel<1>, dim3(N * out_len), dim3(256), 0, st, in, out, bounds_dev, kk_dev, ksize, H, rowbytes, out_len);
+    }
     return hipGetLastError();
 }
 
@@ -175,7 +242,7 @@ hipError_t enhance_launch(const uint8_t* img, uint8_t* tmp, uint8_t* out, unsign
     const int HW = H * W;
     int gx = (HW + 255) / 256;
     if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(gray_sum_kernel, dim3(gx, N), dim3(256), 0, st, img, sums_dev, HW);
+    hipLaunchKernelGGL(gray_sum_kernel, dim3(gx > 64 ? 64 : gx, N), dim3(256), 0, st, img, sums_dev, HW);
     hipLaunchKernelGGL(contrast_kernel, dim3(gx, N), dim3(256), 0, st, img, tmp, sums_dev, HW, contrast);
     hipLaunchKernelGGL(sharpen_kernel, dim3(gx, N), dim3(256), 0, st, tmp, out, H, W, sharpness);
     return hipGetLastError();

@@ -137,3 +137,17 @@ def test_db_postprocess_structured_maps(engine):
         assert np.array_equal(scores[i, :n].cpu().numpy(), rs), i
         total += n
     assert total > 5
+
+
+def test_fused_head_equals_unfused(engine, det_weights):
+    """head.convt3 fused into head.convt2's epilogue must give the same bf16 map as the two-launch path."""
+    pages = torch.from_numpy(_pages(2, 160, 224, 21)).cuda()
+    engine.load_det(det_weights)
+    engine.set_option("fuse_head", 1)
+    a = engine.det_forward(pages).clone()
+    engine.set_option("fuse_head", 0)
+    b = engine.det_forward(pages).clone()
+    engine.set_option("fuse_head", 1)
+    torch.cuda.synchronize()
+    d = (a.float() - b.float()).abs()
+    assert float(d.max()) <= 2.0 ** -8 and float((d > 0).float().mean()) < 1e-3   # same sums, order of the 64-term dot differs
