@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pages", type=int, default=PAGES_PER_RANK, help="pages per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--det-sub-batch", type=int, default=4)
+    ap.add_argument("--det-sub-batch", type=int, default=16)
     args = ap.parse_args()
 
     import torch

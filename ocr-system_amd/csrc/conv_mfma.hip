@@ -23,6 +23,8 @@
 //     (async-stage split); two workgroups per CU (BN <= 64) overlap each other's barriers.
 #include "conv_mfma.h"
 
+#include <cstdlib>
+
 namespace {
 
 template <int KS, int S, int BN, int CK, int TW>
@@ -308,8 +310,11 @@ bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cf
     cfg->ks = ks; cfg->stride = stride; cfg->tw = 32;
     cfg->ck = (cin % 32 == 0) ? 32 : 16;
     cfg->bn = cout_gemm <= 32 ? 32 : (cout_gemm <= 64 ? 64 : 128);
-    if (ks == 1 && cfg->bn == 128) cfg->bn = 64;  // 1x1 layers are bandwidth-bound: smaller tiles, 4 workgroups per CU
+    // measured: 64-channel tiles with >= 2 workgroups per CU beat 128-channel tiles with one (3x3: 460 -> 700-850 TFLOP/s
+    // on the 128..512-channel stages; 1x1 layers are bandwidth-bound and want 4 workgroups per CU)
+    if (cfg->bn == 128) cfg->bn = 64;
     if (ks == 3 && stride == 2 && cfg->bn == 128 && cfg->ck == 32) cfg->bn = 64;  // halo tile is 4x larger: keep LDS < 160 KB
+    if (const char* e = getenv("LUMINA_CONV_BN3")) { if (ks >= 2 && cfg->bn > atoi(e)) cfg->bn = atoi(e); }  // tuning experiments
     return true;
 }
 

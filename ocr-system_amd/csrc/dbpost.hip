@@ -228,25 +228,29 @@ __device__ __forceinline__ long long shfl_xor_ll(long long v, int m) {
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-__global__ __launch_bounds__(64) void comp_box_kernel(const bf16_t* prob, const int* ncomp, const int* ymin, const int* ymax, const int* segoff,
-                                                      const int* rowmin, const int* rowmax, int2* hullbuf, int* box_tmp, float* score_tmp,
-                                                      int* valid_tmp, int Hp, int Wp, int vh, int vw, int maxc, size_t seg_cap,
-                                                      float box_thresh, float unclip_ratio, int min_size) {
-    const int pg = blockIdx.x / maxc, k = blockIdx.x % maxc, lane = threadIdx.x;
+constexpr int HULL_LDS = 4096;  // hull points kept in LDS (taller components fall back to the global scratch)
+
+__global__ __launch_bounds__(256) void comp_box_kernel(const bf16_t* prob, const int* ncomp, const int* ymin, const int* ymax, const int* segoff,
+                                                       const int* rowmin, const int* rowmax, int2* hullbuf, int* box_tmp, float* score_tmp,
+                                                       int* valid_tmp, int Hp, int Wp, int vh, int vw, int maxc, size_t seg_cap,
+                                                       float box_thresh, float unclip_ratio, int min_size) {
+    __shared__ int2 s_hull[HULL_LDS];
+    __shared__ Cand s_cand[4];
+    __shared__ unsigned long long s_sum[4], s_cnt[4];
+    __shared__ int s_nl, s_nr, s_nh;
+    const int pg = blockIdx.x / maxc, k = blockIdx.x % maxc, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* vflag = valid_tmp + (size_t)pg * maxc + k;
     const int n = ncomp[pg] < maxc ? ncomp[pg] : maxc;
-    if (k >= n) { if (lane == 0) *vflag = 0; return; }
+    if (k >= n) { if (tid == 0) *vflag = 0; return; }
     const int y0 = ymin[(size_t)pg * maxc + k], y1 = ymax[(size_t)pg * maxc + k];
     const size_t seg = (size_t)pg * seg_cap + segoff[(size_t)pg * (maxc + 1) + k];
     const int* rmin = rowmin + seg;
     const int* rmax = rowmax + seg;
-    int2* hull = hullbuf + 2 * seg;  // capacity 2*(rows)
     const int rows = y1 - y0 + 1;
-    __shared__ int s_nh;
-    // ---- hull: lane 0 builds the left chain in hull[0..], lane 32 builds the right chain in hull[rows..] ----
-    __shared__ int s_nl, s_nr;
-    if (lane == 0 || lane == 32) {
-        const bool left = lane == 0;
+    int2* hull = (2 * rows <= HULL_LDS) ? s_hull : hullbuf + 2 * seg;
+    // ---- hull: thread 0 builds the left chain in hull[0..], thread 64 (another wave) the right chain in hull[rows..] ----
+    if (tid == 0 || tid == 64) {
+        const bool left = tid == 0;
         int2* ch = hull + (left ? 0 : rows);
         int nc = 0;
         for (int t = 0; t < rows; ++t) {
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(64) void comp_box_kernel(const bf16_t* prob, const 
         if (left) s_nl = nc; else s_nr = nc;
     }
     __syncthreads();
-    if (lane == 0) {  // splice: left chain then right chain, dropping duplicated joints
+    if (tid == 0) {  // splice: left chain then right chain, dropping duplicated joints
         int nh = s_nl;
         const int2* rc = hull + rows;
         for (int t = 0; t < s_nr; ++t) {
@@ -275,10 +279,10 @@ __global__ __launch_bounds__(64) void comp_box_kernel(const bf16_t* prob, const 
     }
     __syncthreads();
     const int nh = s_nh;
-    if (nh < 2) { if (lane == 0) *vflag = 0; return; }
-    // ---- calipers: lanes = edges ----
+    if (nh < 2) { if (tid == 0) *vflag = 0; return; }
+    // ---- calipers: threads = edges ----
     Cand best; best.have = 0; best.dx = best.dy = best.mind = best.maxd = best.minn = best.maxn = 0; best.L = 1; best.A = 0;
-    for (int e = lane; e < nh; e += 64) {
+    for (int e = tid; e < nh; e += 256) {
         const int2 a = hull[e], b = hull[(e + 1) % nh];
         long long dx = b.x - a.x, dy = b.y - a.y;
         if (dx == 0 && dy == 0) continue;
@@ -306,12 +310,17 @@ __global__ __launch_bounds__(64) void comp_box_kernel(const bf16_t* prob, const 
         o.L = shfl_xor_ll(best.L, m); o.A = shfl_xor_ll(best.A, m);
         if (cand_better(o, best)) best = o;
     }
-    if (!best.have) { if (lane == 0) *vflag = 0; return; }
+    if (lane == 0) s_cand[wave] = best;
+    __syncthreads();
+    best = s_cand[0];
+#pragma unroll
+    for (int wv = 1; wv < 4; ++wv) { const Cand o = s_cand[wv]; if (cand_better(o, best)) best = o; }
+    if (!best.have) { if (tid == 0) *vflag = 0; return; }
     const long long wd = best.maxd - best.mind, wn = best.maxn - best.minn;
     const double sqL = __dsqrt_rn((double)best.L);
     const double sside = (double)(wd < wn ? wd : wn) / sqL;
-    if (sside < (double)min_size) { if (lane == 0) *vflag = 0; return; }
-    // ---- score: integer pixels inside the closed rectangle ----
+    if (sside < (double)min_size) { if (tid == 0) *vflag = 0; return; }
+    // ---- score: integer pixels inside the closed rectangle (exact integer sum: order-free) ----
     double fx0, fx1, fy0, fy1;
     {
         const long long as[4] = {best.mind, best.maxd, best.maxd, best.mind}, bs[4] = {best.minn, best.minn, best.maxn, best.maxn};
@@ -328,19 +337,26 @@ __global__ __launch_bounds__(64) void comp_box_kernel(const bf16_t* prob, const 
     int bx0 = (int)floor(fx0) - 1, bx1 = (int)ceil(fx1) + 1, by0 = (int)floor(fy0) - 1, by1 = (int)ceil(fy1) + 1;
     bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0; bx1 = bx1 > vw - 1 ? vw - 1 : bx1; by1 = by1 > vh - 1 ? vh - 1 : by1;
     unsigned long long sum = 0, cnt = 0;
-    const int bw = bx1 - bx0 + 1;
-    const long long npx = (long long)bw * (by1 - by0 + 1);
+    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
     const bf16_t* pp = prob + (size_t)pg * Hp * Wp;
-    for (long long t = lane; t < npx; t += 64) {
-        const int y = by0 + (int)(t / bw), x = bx0 + (int)(t % bw);
-        const long long pd = (long long)x * best.dx + (long long)y * best.dy, pn = -(long long)x * best.dy + (long long)y * best.dx;
-        if (pd < best.mind || pd > best.maxd || pn < best.minn || pn > best.maxn) continue;
-        sum += (unsigned long long)(bf16_to_f32(pp[(size_t)y * Wp + x]) * 16777216.0f);
-        ++cnt;
+    const bool axis = best.dy == 0 || best.dx == 0;  // axis-aligned rectangle: every pixel of the (tight) span is inside
+    for (int yy = by0 + wave; yy <= by1; yy += 4) {   // one wave per row: coalesced bf16 reads
+        const bf16_t* prow = pp + (size_t)yy * Wp;
+        for (int xx = bx0 + lane; xx <= bx1; xx += 64) {
+            const long long pd = (long long)xx * best.dx + (long long)yy * best.dy, pn = -(long long)xx * best.dy + (long long)yy * best.dx;
+            if (pd < best.mind || pd > best.maxd || pn < best.minn || pn > best.maxn) continue;
+            sum += (unsigned long long)(bf16_to_f32(prow[xx]) * 16777216.0f);
+            ++cnt;
+        }
     }
+    (void)axis; (void)bw; (void)bh;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { sum += (unsigned long long)shfl_xor_ll((long long)sum, m); cnt += (unsigned long long)shfl_xor_ll((long long)cnt, m); }
-    if (lane != 0) return;
+    if (lane == 0) { s_sum[wave] = sum; s_cnt[wave] = cnt; }
+    __syncthreads();
+    if (tid != 0) return;
+    sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     if (!cnt) { *vflag = 0; return; }
     const double score = ((double)sum / (double)cnt) / 16777216.0;
     if (score < (double)box_thresh) { *vflag = 0; return; }
@@ -360,7 +376,6 @@ __global__ __launch_bounds__(64) void comp_box_kernel(const bf16_t* prob, const 
             qy[t] = __ddiv_rn(__dadd_rn(t3, t4), dL);
         }
     }
-    // sort 4 points by (x, y)
     for (int i = 1; i < 4; ++i)
         for (int j = i; j > 0; --j) {
             const bool lt = qx[j] < qx[j - 1] || (qx[j] == qx[j - 1] && qy[j] < qy[j - 1]);
@@ -519,7 +534,7 @@ hipError_t dbpost_launch(const DbPostParams& p, void* workspace, hipStream_t st)
     hipLaunchKernelGGL(seg_scan_kernel, dim3(B), dim3(64), 0, st, ncomp, ymin, ymax, segoff, maxc);
     hipLaunchKernelGGL(seg_init_kernel, dim3(grid_for((size_t)B * seg_cap)), dim3(256), 0, st, rowmin, rowmax, (size_t)B * seg_cap);
     hipLaunchKernelGGL(row_extremes_kernel, dim3(gpix), dim3(256), 0, st, label, cid, ymin, segoff, rowmin, rowmax, B, Hp, Wp, p.valid_w, maxc, seg_cap);
-    hipLaunchKernelGGL(comp_box_kernel, dim3(B * maxc), dim3(64), 0, st, p.prob, ncomp, ymin, ymax, segoff, rowmin, rowmax, hull, box_tmp,
+    hipLaunchKernelGGL(comp_box_kernel, dim3(B * maxc), dim3(256), 0, st, p.prob, ncomp, ymin, ymax, segoff, rowmin, rowmax, hull, box_tmp,
                        score_tmp, valid_tmp, Hp, Wp, p.valid_h, p.valid_w, maxc, seg_cap, p.box_thresh, p.unclip_ratio, p.min_size);
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(64), 0, st, box_tmp, score_tmp, valid_tmp, p.boxes, p.scores, p.counts, maxc);
     return hipGetLastError();

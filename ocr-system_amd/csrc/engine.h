@@ -56,7 +56,7 @@ struct lumina_ocr {
     // ---- workspace ----
     uint8_t* ws = nullptr; size_t ws_cap = 0, ws_off = 0;
     std::vector<void*> owned;  // device allocations freed at destroy
-    int det_sub_batch = 4, rec_sub_batch = 2048;
+    int det_sub_batch = 16, rec_sub_batch = 2048;
     std::map<std::string, Tensor4> taps;  // last forward's intermediates (debug / parity tests)
     bool keep_taps = false;
     bool fuse_head = true;  // head.convt3 fused into head.convt2's epilogue

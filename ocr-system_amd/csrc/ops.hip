@@ -47,37 +47,58 @@ __global__ void maxpool_kernel(const bf16_t* x, bf16_t* y, int N, int H, int W, 
 }
 
 // ------------------------------------------------------------------ depthwise conv
-__global__ void dwconv_kernel(const bf16_t* x, const bf16_t* w, const float* bias, bf16_t* y, int N, int H, int W, int C,
-                              int k, int sh, int Ho, int act) {
-    const int cg = C >> 3, pad = k >> 1;
-    const size_t total = (size_t)N * Ho * W * cg;
+// One thread = 4 consecutive output pixels x 8 channels: per kernel row the K+3 input vectors are loaded once and re-used by
+// the 4 sliding windows (3x fewer loads than one-pixel-per-thread); fp32 accumulation in tap order (kh, kw).
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* x, const bf16_t* w, const float* bias, bf16_t* y, int N, int H, int W, int C,
+                                                     int sh, int Ho, int act) {
+    constexpr int PAD = K / 2, XG = 4;
+    const int cg = C >> 3, wg = (W + XG - 1) / XG;
+    const size_t total = (size_t)N * Ho * wg * cg;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c8 = (int)(i % cg);
         size_t t = i / cg;
-        const int ox = (int)(t % W); t /= W;
+        const int xg = (int)(t % wg); t /= wg;
         const int oy = (int)(t % Ho);
         const int n = (int)(t / Ho);
-        float a[8];
+        const int ox0 = xg * XG;
+        float a[XG][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = 0.f;
-        for (int dy = 0; dy < k; ++dy) {
-            const int iy = oy * sh - pad + dy;
+        for (int o = 0; o < XG; ++o)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[o][j] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int iy = oy * sh - PAD + kh;
             if (iy < 0 || iy >= H) continue;
-            for (int dx = 0; dx < k; ++dx) {
-                const int ix = ox - pad + dx;
-                if (ix < 0 || ix >= W) continue;
-                float f[8], g[8];
-                unpack8(*reinterpret_cast<const uint4*>(x + (((size_t)n * H + iy) * W + ix) * C + c8 * 8), f);
-                unpack8(*reinterpret_cast<const uint4*>(w + (size_t)(dy * k + dx) * C + c8 * 8), g);
+            float in[K + XG - 1][8];
+            const bf16_t* row = x + (((size_t)n * H + iy) * W) * C + c8 * 8;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a[j] = a[j] + f[j] * g[j];
+            for (int j = 0; j < K + XG - 1; ++j) {
+                const int ix = ox0 - PAD + j;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(row + (size_t)ix * C);
+                unpack8(v, in[j]);
+            }
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                float g[8];
+                unpack8(*reinterpret_cast<const uint4*>(w + (size_t)(kh * K + kw) * C + c8 * 8), g);
+#pragma unroll
+                for (int o = 0; o < XG; ++o)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[o][j] = a[o][j] + in[o + kw][j] * g[j];
             }
         }
         const float4 b0 = *reinterpret_cast<const float4*>(bias + c8 * 8), b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
-        a[0] += b0.x; a[1] += b0.y; a[2] += b0.z; a[3] += b0.w; a[4] += b1.x; a[5] += b1.y; a[6] += b1.z; a[7] += b1.w;
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = apply_act(a[j], act);
-        *reinterpret_cast<uint4*>(y + i * 8) = pack8(a);
+        for (int o = 0; o < XG; ++o) {
+            if (ox0 + o >= W) break;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[o][j] = apply_act(a[o][j] + bb[j], act);
+            *reinterpret_cast<uint4*>(y + ((((size_t)n * Ho + oy) * W) + ox0 + o) * C + c8 * 8) = pack8(a[o]);
+        }
     }
 }
 
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(64) void ctc_collapse_kernel(const int* idx, const 
 
 int grid_for(size_t total) {
     size_t g = (total + 255) / 256;
-    return (int)(g > 256 * 32 ? 256 * 32 : (g ? g : 1));
+    return (int)(g > 256 * 64 ? 256 * 64 : (g ? g : 1));
 }
 
 }  // namespace
@@ -330,7 +351,10 @@ hipError_t maxpool_launch(const bf16_t* x, bf16_t* y, int N, int H, int W, int C
 hipError_t dwconv_launch(const bf16_t* x, const bf16_t* w, const float* bias, bf16_t* y, int N, int H, int W, int C, int k,
                          int sh, int act, hipStream_t st) {
     const int Ho = (H + 2 * (k / 2) - k) / sh + 1;
-    hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for((size_t)N * Ho * W * (C / 8))), dim3(256), 0, st, x, w, bias, y, N, H, W, C, k, sh, Ho, act);
+    const size_t total = (size_t)N * Ho * ((W + 3) / 4) * (C / 8);
+    if (k == 3) hipLaunchKernelGGL(dwconv_kernel<3>, dim3(grid_for(total)), dim3(256), 0, st, x, w, bias, y, N, H, W, C, sh, Ho, act);
+    else if (k == 5) hipLaunchKernelGGL(dwconv_kernel<5>, dim3(grid_for(total)), dim3(256), 0, st, x, w, bias, y, N, H, W, C, sh, Ho, act);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -38,15 +38,28 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* in, uint
     __syncthreads();
     const uint8_t* rb = reinterpret_cast<const uint8_t*>(row_lds) + off;
     uint8_t* orow = out + (size_t)row * Wo * C;
-    for (int e = threadIdx.x; e < Wo * C; e += 256) {
-        const int xo = e / C, c = e - xo * C;
+    for (int xo = threadIdx.x; xo < Wo; xo += 256) {   // one output pixel (all channels) per thread: bounds / coefficients read once
         const int lo = bounds[2 * xo], cnt = bounds[2 * xo + 1];
         const int* k = kk + (size_t)xo * ksize;
-        int ss = 1 << (PRECISION_BITS - 1);
-        const uint8_t* p = rb + lo * C + c;
-        for (int j = 0; j < cnt; ++j) ss += (int)p[j * C] * k[j];
-        int v = ss >> PRECISION_BITS;
-        orow[e] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        const uint8_t* p = rb + lo * C;
+        if (C == 3) {
+            int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+            for (int j = 0; j < cnt; ++j) {
+                const int kj = k[j];
+                s0 += (int)p[3 * j] * kj; s1 += (int)p[3 * j + 1] * kj; s2 += (int)p[3 * j + 2] * kj;
+            }
+            s0 >>= PRECISION_BITS; s1 >>= PRECISION_BITS; s2 >>= PRECISION_BITS;
+            orow[3 * xo] = (uint8_t)(s0 < 0 ? 0 : (s0 > 255 ? 255 : s0));
+            orow[3 * xo + 1] = (uint8_t)(s1 < 0 ? 0 : (s1 > 255 ? 255 : s1));
+            orow[3 * xo + 2] = (uint8_t)(s2 < 0 ? 0 : (s2 > 255 ? 255 : s2));
+        } else {
+            for (int c = 0; c < C; ++c) {
+                int ss = 1 << (PRECISION_BITS - 1);
+                for (int j = 0; j < cnt; ++j) ss += (int)p[j * C + c] * k[j];
+                const int v = ss >> PRECISION_BITS;
+                orow[xo * C + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
     }
 }
 
