@@ -165,40 +165,74 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(cons
     }
 
     // ---------------- epilogue: bias + residual + act -> bf16 -> LDS stage -> coalesced store ----------------
-    __syncthreads();
-    unsigned char* stage = smem;
+    // All bias / residual loads are issued back to back BEFORE the barrier (one latency, not one per quad), the
+    // activation switch is hoisted out of the per-element code.
     const int cout_r8 = (p.Cout + 7) & ~7;
     const float* bptr = p.bias + ntile * BN;
+    float4 bias_r[C::NT][4];
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias_r[nt][g] = *reinterpret_cast<const float4*>(bptr + nt * 32 + 8 * g + 4 * h);
+    uint2 res_r[2][C::NT][4];
+    const bool has_res = p.res != nullptr;
+    if (has_res) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int ty = wave * 2 + mt, tx = r;
+            const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
+            const bool pvalid = oy < p.Ho && ox < p.Wo && (p.pix_limit == 0 || oy * p.Wo + ox < p.pix_limit);
+            const bf16_t* rrow = p.res + (((size_t)n_img * p.res_h + (oy >> p.res_shift)) * p.res_w + (ox >> p.res_shift)) * p.res_cstride + ntile * BN;
+#pragma unroll
+            for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cn = nt * 32 + 8 * g + 4 * h;
+                    uint2 rv = make_uint2(0, 0);
+                    if (pvalid && ntile * BN + cn < cout_r8) rv = *reinterpret_cast<const uint2*>(rrow + cn);
+                    res_r[mt][nt][g] = rv;
+                }
+        }
+    }
+    __syncthreads();
+    unsigned char* stage = smem;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = bias_r[nt][g];
+                acc[mt][nt][4 * g + 0] += b4.x; acc[mt][nt][4 * g + 1] += b4.y;
+                acc[mt][nt][4 * g + 2] += b4.z; acc[mt][nt][4 * g + 3] += b4.w;
+                if (has_res) {
+                    const uint2 rv = res_r[mt][nt][g];
+                    acc[mt][nt][4 * g + 0] += __uint_as_float(rv.x << 16); acc[mt][nt][4 * g + 1] += __uint_as_float(rv.x & 0xFFFF0000u);
+                    acc[mt][nt][4 * g + 2] += __uint_as_float(rv.y << 16); acc[mt][nt][4 * g + 3] += __uint_as_float(rv.y & 0xFFFF0000u);
+                }
+            }
+#define FOR_ALL_ACC(expr)                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                               \
+        _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                       \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j) { const float v = acc[mt][nt][j]; acc[mt][nt][j] = (expr); }
+    if (p.act == ACT_RELU) { FOR_ALL_ACC(fmaxf(v, 0.f)) }
+    else if (p.act == ACT_HSWISH) { FOR_ALL_ACC(v * fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f) }
+    else if (p.act == ACT_SIGMOID) { FOR_ALL_ACC(1.f / (1.f + expf(-v))) }
+    else if (p.act == ACT_HSIGMOID) { FOR_ALL_ACC(fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f)) }
+#undef FOR_ALL_ACC
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const int ty = wave * 2 + mt, tx = r;
-        const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
-        const bool pvalid = oy < p.Ho && ox < p.Wo && (p.pix_limit == 0 || oy * p.Wo + ox < p.pix_limit);
-        const int tp = ty * TW + tx;
-        const bf16_t* rrow = nullptr;
-        if (p.res != nullptr && pvalid)
-            rrow = p.res + (((size_t)n_img * p.res_h + (oy >> p.res_shift)) * p.res_w + (ox >> p.res_shift)) * p.res_cstride + ntile * BN;
+        const int tp = (wave * 2 + mt) * TW + r;
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) {
+        for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cn = nt * 32 + 8 * g + 4 * h;
-                const float4 b4 = *reinterpret_cast<const float4*>(bptr + cn);
-                float v0 = acc[mt][nt][4 * g + 0] + b4.x, v1 = acc[mt][nt][4 * g + 1] + b4.y;
-                float v2 = acc[mt][nt][4 * g + 2] + b4.z, v3 = acc[mt][nt][4 * g + 3] + b4.w;
-                if (rrow != nullptr && ntile * BN + cn < cout_r8) {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(rrow + cn);
-                    v0 += __uint_as_float(rv.x << 16); v1 += __uint_as_float(rv.x & 0xFFFF0000u);
-                    v2 += __uint_as_float(rv.y << 16); v3 += __uint_as_float(rv.y & 0xFFFF0000u);
-                }
-                v0 = apply_act(v0, p.act); v1 = apply_act(v1, p.act);
-                v2 = apply_act(v2, p.act); v3 = apply_act(v3, p.act);
                 uint2 o;
-                o.x = pack_bf16x2(v0, v1);
-                o.y = pack_bf16x2(v2, v3);
+                o.x = pack_bf16x2(acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1]);
+                o.y = pack_bf16x2(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
                 *reinterpret_cast<uint2*>(stage + tp * C::STAGE_PITCH + cn * 2) = o;
             }
-        }
     }
     __syncthreads();
     if (p.out_mode == OUT_CONVT && p.fuse_w != nullptr) {
