@@ -236,32 +236,31 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(cons
     }
     __syncthreads();
     if (p.out_mode == OUT_CONVT && p.fuse_w != nullptr) {
-        // one thread per tile pixel and per 64-channel group q of this cout tile: 4 dot products -> sigmoid -> 2x2 block
-        const int tp = tid;
-        const int ty = tp / TW, tx = tp - ty * TW;
-        const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
-        if (oy < p.Ho && ox < p.Wo) {
-            const int cc = p.convt_c;  // 64
-            for (int qq = 0; qq < BN / 64; ++qq) {
-                const int q = (ntile * BN) / cc + qq;
-                float a0 = p.fuse_b, a1 = p.fuse_b, a2 = p.fuse_b, a3 = p.fuse_b;
-                for (int c8 = 0; c8 < 8; ++c8) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(stage + tp * C::STAGE_PITCH + qq * 128 + c8 * 16);
-                    const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+        // Fused DBHead tail on the matrix cores: D2[q2][pixel] = W3[q2][c] * act[c][pixel] (K = 64, rows >= 4 of W3 are zero).
+        // B fragments come straight from the staged bf16 tile (row pitch 144 B: conflict-free b128 reads), A fragments from the
+        // 2 KB pre-packed weight image [kstep][half][32][8]; lanes with h == 0 end up with the 4 outputs of their pixel.
+        if constexpr (BN == 64) {
+            const int q = ntile;  // convt_c == 64: one sub-pixel per cout tile
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float x = __uint_as_float((j & 1) ? (vv[j >> 1] & 0xFFFF0000u) : (vv[j >> 1] << 16));
-                        const int c = c8 * 8 + j;
-                        a0 = a0 + x * bf16_to_f32(p.fuse_w[0 * cc + c]);
-                        a1 = a1 + x * bf16_to_f32(p.fuse_w[1 * cc + c]);
-                        a2 = a2 + x * bf16_to_f32(p.fuse_w[2 * cc + c]);
-                        a3 = a3 + x * bf16_to_f32(p.fuse_w[3 * cc + c]);
-                    }
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x16_t d2;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) d2[j] = 0.f;
+                const int tp = (wave * 2 + mt) * TW + r;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8_t bfr = lds_frag(stage + tp * C::STAGE_PITCH + (ks * 16 + h * 8) * 2);
+                    const bf16x8_t afr = *reinterpret_cast<const bf16x8_t*>(p.fuse_w + ((ks * 2 + h) * 32 + r) * 8);
+                    d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, d2, 0, 0, 0);
                 }
-                const int yy = 4 * oy + 2 * (q >> 1), xx = 4 * ox + 2 * (q & 1);
-                bf16_t* dst = p.y + ((size_t)n_img * (4 * p.Ho) + yy) * (size_t)(4 * p.Wo) + xx;
-                *reinterpret_cast<uint32_t*>(dst) = pack_bf16x2(apply_act(a0, ACT_SIGMOID), apply_act(a1, ACT_SIGMOID));
-                *reinterpret_cast<uint32_t*>(dst + 4 * p.Wo) = pack_bf16x2(apply_act(a2, ACT_SIGMOID), apply_act(a3, ACT_SIGMOID));
+                const int ty = wave * 2 + mt, tx = r;
+                const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
+                if (h == 0 && oy < p.Ho && ox < p.Wo) {
+                    const int yy = 4 * oy + 2 * (q >> 1), xx = 4 * ox + 2 * (q & 1);
+                    bf16_t* dst = p.y + ((size_t)n_img * (4 * p.Ho) + yy) * (size_t)(4 * p.Wo) + xx;
+                    *reinterpret_cast<uint32_t*>(dst) = pack_bf16x2(apply_act(d2[0] + p.fuse_b, ACT_SIGMOID), apply_act(d2[1] + p.fuse_b, ACT_SIGMOID));
+                    *reinterpret_cast<uint32_t*>(dst + 4 * p.Wo) = pack_bf16x2(apply_act(d2[2] + p.fuse_b, ACT_SIGMOID), apply_act(d2[3] + p.fuse_b, ACT_SIGMOID));
+                }
             }
         }
         return;

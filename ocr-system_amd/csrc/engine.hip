@@ -173,7 +173,15 @@ int eng_load_det(lumina_ocr* eng, const void* blob, size_t n) {
         ConvLayer& Lf = eng->det["head.convt2.fused"];
         Lf = L;
         Lf.name = "head.convt2+3";
-        Lf.fuse_w = static_cast<bf16_t*>(dev_upload(eng, w3->data, 4 * 64 * sizeof(bf16_t)));
+        {   // MFMA A-operand image [kstep 4][half 2][row 32][8]: rows 0..3 = convt3 weights, the rest zero
+            const bf16_t* w3s = reinterpret_cast<const bf16_t*>(w3->data);
+            std::vector<bf16_t> img(4 * 2 * 32 * 8, 0);
+            for (int ks = 0; ks < 4; ++ks)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int row = 0; row < 4; ++row)
+                        for (int j = 0; j < 8; ++j) img[((ks * 2 + hh) * 32 + row) * 8 + j] = w3s[row * 64 + ks * 16 + hh * 8 + j];
+            Lf.fuse_w = static_cast<bf16_t*>(dev_upload(eng, img.data(), img.size() * sizeof(bf16_t)));
+        }
         Lf.fuse_b = reinterpret_cast<const float*>(b3->data)[0];
         if (!Lf.fuse_w) return locr_fail(eng, "upload", "head.convt3 fused weights");
     }

@@ -159,41 +159,88 @@ __global__ void se_scale_kernel(const bf16_t* x, const bf16_t* gate, bf16_t* y, 
     }
 }
 
-// ------------------------------------------------------------------ LSTM recurrence
-// One block = one (sequence, direction); 384 threads = 4 gates x 96 hidden rows; W_hh row in registers.
-constexpr int LH = 96;
-__global__ __launch_bounds__(384) void lstm_kernel(const bf16_t* xproj, const bf16_t* whh, bf16_t* out, int T) {
-    __shared__ float hs[LH];
-    __shared__ float gs[4 * LH];
-    const int n = blockIdx.x >> 1, dir = blockIdx.x & 1, tid = threadIdx.x;
-    float wr[LH];
-    const bf16_t* wrow = whh + ((size_t)dir * 4 * LH + tid) * LH;
+// ------------------------------------------------------------------ LSTM recurrence on the matrix cores
+// One workgroup = 32 sequences x one direction, 3 waves; wave u owns hidden units [32u, 32u+32).  Per time step
+//   gates[4][32 units][32 seqs] = W_hh (A operand, resident in registers for all 80 steps) * h_{t-1} (B operand, LDS)
+// with the accumulators initialised from the stored x-projection.  The four gate tiles of a (unit, sequence) pair
+// land in the same lane / register slot, so the cell update is register-local; h_t goes to LDS (next step's operand)
+// and to HBM (layer output) as packed 8-byte quads.  c stays fp32 in registers, h is bf16 (oracle/nets.py lstm_dir).
+constexpr int LH = 96, LSEQ = 32, LPITCH = 208;  // bytes per sequence row of the h buffer (192 + 16: conflict-free b128 reads)
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.f * fast_sigmoid(2.f * x) - 1.f; }
+
+__global__ __launch_bounds__(192) void lstm_kernel(const bf16_t* xproj, const bf16_t* whh, bf16_t* out, int N, int T) {
+    __shared__ __attribute__((aligned(16))) unsigned char hbuf[2][LSEQ * LPITCH];
+    const int tid = threadIdx.x, lane = tid & 63, u = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int dir = blockIdx.x & 1, n0 = (blockIdx.x >> 1) * LSEQ;
+    const int seq = n0 + r;
+    const bool valid = seq < N;
+    const int sq = valid ? seq : N - 1;  // clamp loads of the ragged last group
+    bf16x8_t afr[4][6];
 #pragma unroll
-    for (int k = 0; k < LH; k += 8) {
-        float f[8];
-        unpack8(*reinterpret_cast<const uint4*>(wrow + k), f);
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wr[k + j] = f[j];
+        for (int ks = 0; ks < 6; ++ks)
+            afr[g][ks] = *reinterpret_cast<const bf16x8_t*>(whh + ((size_t)dir * 4 * LH + g * LH + 32 * u + r) * LH + ks * 16 + h * 8);
+    for (int i = tid; i < 2 * LSEQ * LPITCH / 16; i += 192) reinterpret_cast<uint4*>(&hbuf[0][0])[i] = make_uint4(0, 0, 0, 0);
+    float c[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c[j] = 0.f;
+    const size_t xrow = (size_t)sq * T;
+    const int xcol = dir * 4 * LH + 32 * u + 4 * h;
+    uint2 xq[4][4];
+    {
+        const int t = dir ? T - 1 : 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xq[g][q] = *reinterpret_cast<const uint2*>(xproj + (xrow + t) * (8 * LH) + xcol + g * LH + 8 * q);
     }
-    if (tid < LH) hs[tid] = 0.f;
-    float c = 0.f;
     __syncthreads();
+    int cur = 0;
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
-        float pre = bf16_to_f32(xproj[((size_t)n * T + t) * (8 * LH) + dir * 4 * LH + tid]);
+        f32x16_t acc[4];
 #pragma unroll
-        for (int k = 0; k < LH; ++k) pre = pre + wr[k] * hs[k];
-        gs[tid] = pre;
-        __syncthreads();
-        if (tid < LH) {
-            const float ig = 1.f / (1.f + expf(-gs[tid])), fg = 1.f / (1.f + expf(-gs[LH + tid]));
-            const float gg = tanhf(gs[2 * LH + tid]), og = 1.f / (1.f + expf(-gs[3 * LH + tid]));
-            c = fg * c + ig * gg;
-            const bf16_t hb = f32_to_bf16(og * tanhf(c));
-            hs[tid] = bf16_to_f32(hb);
-            out[((size_t)n * T + t) * (2 * LH) + dir * LH + tid] = hb;
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[g][4 * q + 0] = __uint_as_float(xq[g][q].x << 16); acc[g][4 * q + 1] = __uint_as_float(xq[g][q].x & 0xFFFF0000u);
+                acc[g][4 * q + 2] = __uint_as_float(xq[g][q].y << 16); acc[g][4 * q + 3] = __uint_as_float(xq[g][q].y & 0xFFFF0000u);
+            }
+        if (step + 1 < T) {  // prefetch the next step's x-projection under this step's MFMAs
+            const int tn = dir ? (t - 1) : (t + 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xq[g][q] = *reinterpret_cast<const uint2*>(xproj + (xrow + tn) * (8 * LH) + xcol + g * LH + 8 * q);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const bf16x8_t bfr = *reinterpret_cast<const bf16x8_t*>(&hbuf[cur][r * LPITCH + (ks * 16 + h * 8) * 2]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[g][ks], bfr, acc[g], 0, 0, 0);
+        }
+        bf16_t* orow = out + ((size_t)sq * T + t) * (2 * LH) + dir * LH + 32 * u + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float hn[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 4 * q + e;
+                const float ig = fast_sigmoid(acc[0][j]), fg = fast_sigmoid(acc[1][j]), gg = fast_tanh(acc[2][j]), og = fast_sigmoid(acc[3][j]);
+                c[j] = fg * c[j] + ig * gg;
+                hn[e] = og * fast_tanh(c[j]);
+            }
+            uint2 o;
+            o.x = pack_bf16x2(hn[0], hn[1]);
+            o.y = pack_bf16x2(hn[2], hn[3]);
+            *reinterpret_cast<uint2*>(&hbuf[cur ^ 1][r * LPITCH + (32 * u + 8 * q + 4 * h) * 2]) = o;
+            if (valid) *reinterpret_cast<uint2*>(orow + 8 * q) = o;
         }
         __syncthreads();
+        cur ^= 1;
     }
 }
 
@@ -290,14 +337,14 @@ __global__ __launch_bounds__(256, 1) void ctc_fc_argmax_kernel(const CtcFcParams
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) ts += expf(acc[mt][nt][j] - tm);
+                for (int j = 0; j < 16; ++j) ts += __builtin_amdgcn_exp2f((acc[mt][nt][j] - tm) * 1.4426950408889634f);
             ts += __shfl_xor(ts, 32);
             if (tm > run_m[mt]) {
-                run_s[mt] = run_s[mt] * expf(run_m[mt] - tm) + ts;
+                run_s[mt] = run_s[mt] * __builtin_amdgcn_exp2f((run_m[mt] - tm) * 1.4426950408889634f) + ts;
                 run_m[mt] = tm;
                 run_i[mt] = tile * CT_BN + ti;
             } else {
-                run_s[mt] += ts * expf(tm - run_m[mt]);
+                run_s[mt] += ts * __builtin_amdgcn_exp2f((tm - run_m[mt]) * 1.4426950408889634f);
             }
         }
     }
@@ -372,7 +419,7 @@ hipError_t se_scale_launch(const bf16_t* x, const bf16_t* gate, bf16_t* y, int N
 }
 
 hipError_t lstm_recurrent_launch(const bf16_t* xproj, const bf16_t* whh, bf16_t* out, int N, int T, hipStream_t st) {
-    hipLaunchKernelGGL(lstm_kernel, dim3(N * 2), dim3(384), 0, st, xproj, whh, out, T);
+    hipLaunchKernelGGL(lstm_kernel, dim3(((N + LSEQ - 1) / LSEQ) * 2), dim3(192), 0, st, xproj, whh, out, N, T);
     return hipGetLastError();
 }
 
