@@ -32,7 +32,7 @@ struct ConvParams {
 };
 
 struct ConvKernelCfg {
-    int ks, stride, bn, ck, tw;
+    int ks, stride, bn, ck, tw, nw;  // nw: waves per workgroup (4 = 8x32-pixel tile; 8 = 16x32, double-buffered LDS)
 };
 
 // Size in bytes of the packed weight image for (cout, ks, cin) under cfg.

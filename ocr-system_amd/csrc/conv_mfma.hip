@@ -27,9 +27,10 @@
 
 namespace {
 
-template <int KS, int S, int BN, int CK, int TW>
+template <int KS, int S, int BN, int CK, int TW, int NW = 4, int DB = 0>
 struct Cfg {
-    static constexpr int TH = 256 / TW;
+    static constexpr int NTHR = NW * 64;
+    static constexpr int TH = NTHR / TW;
     static constexpr int PAD = (KS == 3) ? 1 : 0;
     static constexpr int HH = (TH - 1) * S + KS;
     static constexpr int HW = (TW - 1) * S + KS;
@@ -45,20 +46,22 @@ struct Cfg {
     static constexpr int A_BYTES = PLANE_A * NPL * 16;
     static constexpr int W_BYTES = PLANE_W * NPL * 16;
     static constexpr int STAGE_PITCH = BN * 2 + 16;
-    static constexpr int STAGE_BYTES = 256 * STAGE_PITCH;
-    static constexpr int LDS_BYTES = (A_BYTES + W_BYTES) > STAGE_BYTES ? (A_BYTES + W_BYTES) : STAGE_BYTES;
+    static constexpr int STAGE_BYTES = NTHR * STAGE_PITCH;
+    static constexpr int BUF_BYTES = A_BYTES + W_BYTES;
+    static constexpr int LDS_BYTES = (BUF_BYTES * (DB ? 2 : 1)) > STAGE_BYTES ? (BUF_BYTES * (DB ? 2 : 1)) : STAGE_BYTES;
     static constexpr int A_ITEMS = HH * HW * NPL;
-    static constexpr int AIT = (A_ITEMS + 255) / 256;
+    static constexpr int AIT = (A_ITEMS + NTHR - 1) / NTHR;
     static constexpr int W_ITEMS = WROWS * NPL;
-    static constexpr int WIT = (W_ITEMS + 255) / 256;
+    static constexpr int WIT = (W_ITEMS + NTHR - 1) / NTHR;
     static constexpr int CPP = BN / 8;  // 16-byte chunks per pixel in the store pass
 };
 
 __device__ __forceinline__ bf16x8_t lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 
-template <int KS, int S, int BN, int CK, int TW>
-__global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(const ConvParams p) {
-    using C = Cfg<KS, S, BN, CK, TW>;
+template <int KS, int S, int BN, int CK, int TW, int NW, int DB>
+__global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void conv_mfma_kernel(const ConvParams p) {
+    using C = Cfg<KS, S, BN, CK, TW, NW, DB>;
+    constexpr int NTHR = C::NTHR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;
     unsigned char* sW = smem + C::A_BYTES;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(cons
     const int iy0 = tile_y * C::TH * S - C::PAD, ix0 = tile_x * TW * S - C::PAD;
 #pragma unroll
     for (int it = 0; it < C::AIT; ++it) {
-        const int i = tid + 256 * it;
+        const int i = tid + NTHR * it;
         const int pi = i / C::NPL, c = i - pi * C::NPL;
         const int hy = pi / C::HW, hx = pi - hy * C::HW;
         const int iy = iy0 + hy, ix = ix0 + hx;
@@ -104,19 +107,19 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(cons
         }                                                                                            \
         const uint4* wsrc = reinterpret_cast<const uint4*>(wbase + (size_t)(chunk_) * C::W_ITEMS * 8); \
         _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
-            const int i = tid + 256 * it;                                                            \
+            const int i = tid + NTHR * it;                                                           \
             uint4 t_ = make_uint4(0, 0, 0, 0);                                                       \
-            if (C::W_ITEMS % 256 == 0 || i < C::W_ITEMS) t_ = wsrc[i];                               \
+            if (C::W_ITEMS % NTHR == 0 || i < C::W_ITEMS) t_ = wsrc[i];                              \
             w_reg[it] = t_;                                                                          \
         }                                                                                            \
     }
-#define WRITE_LDS()                                                                                  \
+#define WRITE_LDS(boff_)                                                                             \
     {                                                                                                \
         _Pragma("unroll") for (int it = 0; it < C::AIT; ++it)                                        \
-            if (a_loff[it] >= 0) *reinterpret_cast<uint4*>(sA + a_loff[it]) = a_reg[it];             \
+            if (a_loff[it] >= 0) *reinterpret_cast<uint4*>(sA + (boff_) + a_loff[it]) = a_reg[it];   \
         _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
-            const int i = tid + 256 * it;                                                            \
-            if (C::W_ITEMS % 256 == 0 || i < C::W_ITEMS) *reinterpret_cast<uint4*>(sW + i * 16) = w_reg[it]; \
+            const int i = tid + NTHR * it;                                                           \
+            if (C::W_ITEMS % NTHR == 0 || i < C::W_ITEMS) *reinterpret_cast<uint4*>(sW + (boff_) + i * 16) = w_reg[it]; \
         }                                                                                            \
     }
 
@@ -137,32 +140,43 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(cons
     }
     const int woff = (h * C::PLANE_W + r) * 16;
 
+#define COMPUTE_CHUNK(boff_)                                                                                       \
+    _Pragma("unroll") for (int tap = 0; tap < C::TAPS; ++tap) {                                                    \
+        const int kh = tap / KS, kw = tap - kh * KS;                                                               \
+        _Pragma("unroll") for (int kc = 0; kc < CK / 16; ++kc) {                                                   \
+            bf16x8_t bfr[2], afr[C::NT];                                                                           \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                       \
+                bfr[mt] = lds_frag(sA + (boff_) + aoff[mt] + ((2 * kc) * C::PLANE_A + kh * C::HWP + kw) * 16);      \
+            _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                                                   \
+                afr[nt] = lds_frag(sW + (boff_) + woff + ((2 * kc) * C::PLANE_W + tap * BN + nt * 32) * 16);       \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                       \
+                _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                                               \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[nt], bfr[mt], acc[mt][nt], 0, 0, 0); \
+        }                                                                                                          \
+    }
     ISSUE_LOADS(0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if constexpr (DB) {
+        // double-buffered LDS, ONE barrier per chunk: loads of chunk c+1 fly under the MFMAs of chunk c and are written to
+        // the other buffer afterwards; the barrier both publishes that buffer and retires every read of the current one.
+        WRITE_LDS(0);
         __syncthreads();
-        WRITE_LDS();
-        __syncthreads();
-        if (chunk + 1 < nchunks) ISSUE_LOADS(chunk + 1);
-#pragma unroll
-        for (int tap = 0; tap < C::TAPS; ++tap) {
-            const int kh = tap / KS, kw = tap - kh * KS;
-#pragma unroll
-            for (int kc = 0; kc < CK / 16; ++kc) {
-                bf16x8_t bfr[2], afr[C::NT];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    bfr[mt] = lds_frag(sA + aoff[mt] + ((2 * kc) * C::PLANE_A + kh * C::HWP + kw) * 16);
-#pragma unroll
-                for (int nt = 0; nt < C::NT; ++nt)
-                    afr[nt] = lds_frag(sW + woff + ((2 * kc) * C::PLANE_W + tap * BN + nt * 32) * 16);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < C::NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[nt], bfr[mt], acc[mt][nt], 0, 0, 0);
-            }
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int boff = (chunk & 1) * C::BUF_BYTES;
+            if (chunk + 1 < nchunks) ISSUE_LOADS(chunk + 1);
+            COMPUTE_CHUNK(boff)
+            if (chunk + 1 < nchunks) WRITE_LDS(C::BUF_BYTES - boff);
+            __syncthreads();
+        }
+    } else {
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            __syncthreads();
+            WRITE_LDS(0);
+            __syncthreads();
+            if (chunk + 1 < nchunks) ISSUE_LOADS(chunk + 1);
+            COMPUTE_CHUNK(0)
         }
     }
+#undef COMPUTE_CHUNK
 
     // ---------------- epilogue: bias + residual + act -> bf16 -> LDS stage -> coalesced store ----------------
     // All bias / residual loads are issued back to back BEFORE the barrier (one latency, not one per quad), the
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(cons
     }
 #pragma unroll
     for (int k = 0; k < C::CPP; ++k) {
-        const int i = tid + 256 * k;
+        const int i = tid + NTHR * k;
         const int tp = i / C::CPP, ch = i - tp * C::CPP;
         const int ty = tp / TW, tx = tp - ty * TW;
         const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
@@ -300,10 +314,10 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(cons
     }
 }
 
-template <int KS, int S, int BN, int CK, int TW>
+template <int KS, int S, int BN, int CK, int TW, int NW = 4, int DB = 0>
 hipError_t launch_t(const ConvParams& p, hipStream_t stream) {
-    using C = Cfg<KS, S, BN, CK, TW>;
-    auto kern = conv_mfma_kernel<KS, S, BN, CK, TW>;
+    using C = Cfg<KS, S, BN, CK, TW, NW, DB>;
+    auto kern = conv_mfma_kernel<KS, S, BN, CK, TW, NW, DB>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -311,7 +325,7 @@ hipError_t launch_t(const ConvParams& p, hipStream_t stream) {
         attr_done = true;
     }
     const int grid = p.N * p.tiles_x * p.tiles_y * p.n_tiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, p);
     return hipGetLastError();
 }
 
@@ -340,20 +354,22 @@ void pack_conv_weights(const bf16_t* ohwi, int cout_gemm, int ks, int cin, int b
 bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cfg) {
     if (!((ks == 1 && stride == 1) || (ks == 2 && stride == 2) || (ks == 3 && (stride == 1 || stride == 2)))) return false;
     if (cin % 16 != 0) return false;
-    cfg->ks = ks; cfg->stride = stride; cfg->tw = 32;
+    cfg->ks = ks; cfg->stride = stride; cfg->tw = 32; cfg->nw = 4;
     cfg->ck = (cin % 32 == 0) ? 32 : 16;
     cfg->bn = cout_gemm <= 32 ? 32 : (cout_gemm <= 64 ? 64 : 128);
     // measured: 64-channel tiles with >= 2 workgroups per CU beat 128-channel tiles with one (3x3: 460 -> 700-850 TFLOP/s
     // on the 128..512-channel stages; 1x1 layers are bandwidth-bound and want 4 workgroups per CU)
     if (cfg->bn == 128) cfg->bn = 64;
     if (ks == 3 && stride == 2 && cfg->bn == 128 && cfg->ck == 32) cfg->bn = 64;  // halo tile is 4x larger: keep LDS < 160 KB
-    if (const char* e = getenv("LUMINA_CONV_BN3")) { if (ks >= 2 && cfg->bn > atoi(e)) cfg->bn = atoi(e); }  // tuning experiments
+    // The 8-wave / 16x32-tile / double-buffered-LDS variant (one workgroup per CU, one barrier per chunk) measured SLOWER
+    // than two independent 4-wave workgroups per CU (572 vs 601 TFLOP/s over DBNet): it stays available for experiments.
+    if (const char* e = getenv("LUMINA_CONV_NW")) { if (atoi(e) == 8 && ks == 3 && stride == 1 && cfg->bn == 64 && cfg->ck == 32 && cin >= 64) cfg->nw = 8; }
     return true;
 }
 
 const char* conv_kernel_name(const ConvKernelCfg& c) {
     static thread_local char buf[64];
-    snprintf(buf, sizeof(buf), "conv_mfma<k%d,s%d,bn%d,ck%d>", c.ks, c.stride, c.bn, c.ck);
+    snprintf(buf, sizeof(buf), "conv_mfma<k%d,s%d,bn%d,ck%d,w%d>", c.ks, c.stride, c.bn, c.ck, c.nw);
     return buf;
 }
 
@@ -362,8 +378,12 @@ const char* conv_kernel_name(const ConvKernelCfg& c) {
 
 hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t stream) {
     p.tiles_x = ceil_div(p.Wo, 32);
-    p.tiles_y = ceil_div(p.Ho, 8);
+    p.tiles_y = ceil_div(p.Ho, cfg.nw * 2);
     p.n_tiles = ceil_div(p.Cout, cfg.bn);
+    if (cfg.nw == 8) {  // 512-thread, double-buffered variant (3x3/s1, multi-chunk layers)
+        if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 32) return launch_t<3, 1, 64, 32, 32, 8, 1>(p, stream);
+        return hipErrorInvalidValue;
+    }
     DISPATCH(3, 1, 32, 32) DISPATCH(3, 1, 64, 32) DISPATCH(3, 1, 128, 32)
     DISPATCH(3, 2, 32, 32) DISPATCH(3, 2, 64, 32)
     DISPATCH(1, 1, 32, 32) DISPATCH(1, 1, 64, 32) DISPATCH(1, 1, 128, 32)
