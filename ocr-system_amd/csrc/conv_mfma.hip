@@ -30,7 +30,9 @@ namespace {
 template <int KS, int S, int BN, int CK, int TW, int NW = 4, int DB = 0>
 struct Cfg {
     static constexpr int NTHR = NW * 64;
-    static constexpr int TH = NTHR / TW;
+    static constexpr bool PP = (DB == 2);           // ping-pong: two 4-wave groups alternate compute / stage roles
+    static constexpr int GTHR = PP ? 256 : NTHR;    // threads that cooperate on one LDS buffer
+    static constexpr int TH = GTHR / TW;
     static constexpr int PAD = (KS == 3) ? 1 : 0;
     static constexpr int HH = (TH - 1) * S + KS;
     static constexpr int HW = (TW - 1) * S + KS;
@@ -46,13 +48,14 @@ struct Cfg {
     static constexpr int A_BYTES = PLANE_A * NPL * 16;
     static constexpr int W_BYTES = PLANE_W * NPL * 16;
     static constexpr int STAGE_PITCH = BN * 2 + 16;
-    static constexpr int STAGE_BYTES = NTHR * STAGE_PITCH;
+    static constexpr int STAGE_BYTES = GTHR * STAGE_PITCH;
     static constexpr int BUF_BYTES = A_BYTES + W_BYTES;
-    static constexpr int LDS_BYTES = (BUF_BYTES * (DB ? 2 : 1)) > STAGE_BYTES ? (BUF_BYTES * (DB ? 2 : 1)) : STAGE_BYTES;
+    static constexpr int XCHG_BYTES = PP ? 256 * 2 * NT * 16 * 4 : 0;  // fp32 accumulators of the second group
+    static constexpr int LDS_BYTES = (BUF_BYTES * (DB ? 2 : 1)) > (XCHG_BYTES + STAGE_BYTES) ? (BUF_BYTES * (DB ? 2 : 1)) : (XCHG_BYTES + STAGE_BYTES);
     static constexpr int A_ITEMS = HH * HW * NPL;
-    static constexpr int AIT = (A_ITEMS + NTHR - 1) / NTHR;
+    static constexpr int AIT = (A_ITEMS + GTHR - 1) / GTHR;
     static constexpr int W_ITEMS = WROWS * NPL;
-    static constexpr int WIT = (W_ITEMS + NTHR - 1) / NTHR;
+    static constexpr int WIT = (W_ITEMS + GTHR - 1) / GTHR;
     static constexpr int CPP = BN / 8;  // 16-byte chunks per pixel in the store pass
 };
 
@@ -61,12 +64,16 @@ __device__ __forceinline__ bf16x8_t lds_frag(const unsigned char* p) { return *r
 template <int KS, int S, int BN, int CK, int TW, int NW, int DB>
 __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void conv_mfma_kernel(const ConvParams p) {
     using C = Cfg<KS, S, BN, CK, TW, NW, DB>;
-    constexpr int NTHR = C::NTHR;
+    constexpr int NTHR = C::NTHR, GTHR = C::GTHR;
+    constexpr bool PP = C::PP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;
-    unsigned char* sW = smem + C::A_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = PP ? (tid >> 8) : 0;            // ping-pong group (0/1)
+    const int wave = PP ? ((tid >> 6) & 3) : (tid >> 6);  // wave index inside its group: owns pixel rows 2*wave, 2*wave+1
+    const int gtid = PP ? (tid & 255) : tid;
+    unsigned char* sA = smem + (PP ? grp * C::BUF_BYTES : 0);
+    unsigned char* sW = sA + C::A_BYTES;
     const int r = lane & 31, h = lane >> 5;
 
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     const int iy0 = tile_y * C::TH * S - C::PAD, ix0 = tile_x * TW * S - C::PAD;
 #pragma unroll
     for (int it = 0; it < C::AIT; ++it) {
-        const int i = tid + NTHR * it;
+        const int i = gtid + GTHR * it;
         const int pi = i / C::NPL, c = i - pi * C::NPL;
         const int hy = pi / C::HW, hx = pi - hy * C::HW;
         const int iy = iy0 + hy, ix = ix0 + hx;
@@ -107,9 +114,9 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         }                                                                                            \
         const uint4* wsrc = reinterpret_cast<const uint4*>(wbase + (size_t)(chunk_) * C::W_ITEMS * 8); \
         _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
-            const int i = tid + NTHR * it;                                                           \
+            const int i = gtid + GTHR * it;                                                          \
             uint4 t_ = make_uint4(0, 0, 0, 0);                                                       \
-            if (C::W_ITEMS % NTHR == 0 || i < C::W_ITEMS) t_ = wsrc[i];                              \
+            if (C::W_ITEMS % GTHR == 0 || i < C::W_ITEMS) t_ = wsrc[i];                              \
             w_reg[it] = t_;                                                                          \
         }                                                                                            \
     }
@@ -118,8 +125,8 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         _Pragma("unroll") for (int it = 0; it < C::AIT; ++it)                                        \
             if (a_loff[it] >= 0) *reinterpret_cast<uint4*>(sA + (boff_) + a_loff[it]) = a_reg[it];   \
         _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
-            const int i = tid + NTHR * it;                                                           \
-            if (C::W_ITEMS % NTHR == 0 || i < C::W_ITEMS) *reinterpret_cast<uint4*>(sW + (boff_) + i * 16) = w_reg[it]; \
+            const int i = gtid + GTHR * it;                                                          \
+            if (C::W_ITEMS % GTHR == 0 || i < C::W_ITEMS) *reinterpret_cast<uint4*>(sW + (boff_) + i * 16) = w_reg[it]; \
         }                                                                                            \
     }
 
@@ -140,22 +147,52 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     }
     const int woff = (h * C::PLANE_W + r) * 16;
 
-#define COMPUTE_CHUNK(boff_)                                                                                       \
-    _Pragma("unroll") for (int tap = 0; tap < C::TAPS; ++tap) {                                                    \
-        const int kh = tap / KS, kw = tap - kh * KS;                                                               \
-        _Pragma("unroll") for (int kc = 0; kc < CK / 16; ++kc) {                                                   \
-            bf16x8_t bfr[2], afr[C::NT];                                                                           \
-            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                       \
-                bfr[mt] = lds_frag(sA + (boff_) + aoff[mt] + ((2 * kc) * C::PLANE_A + kh * C::HWP + kw) * 16);      \
-            _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                                                   \
-                afr[nt] = lds_frag(sW + (boff_) + woff + ((2 * kc) * C::PLANE_W + tap * BN + nt * 32) * 16);       \
-            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                       \
-                _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                                               \
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[nt], bfr[mt], acc[mt][nt], 0, 0, 0); \
-        }                                                                                                          \
+    // Fragment reads are software-pipelined one (tap, k-step) ahead of the MFMAs that consume them: the reads of step s+1 are
+    // in flight while the 2*NT MFMAs of step s issue (hipcc otherwise places every ds_read right in front of its MFMA and the
+    // wave idles for the LDS latency once per step).
+    constexpr int NSTEPS = C::TAPS * (CK / 16);
+    bf16x8_t bfr[2][2], afr[2][C::NT];
+#define LOAD_FRAGS(boff_, st_, set_)                                                                               \
+    {                                                                                                              \
+        const int tap_ = (st_) / (CK / 16), kc_ = (st_) % (CK / 16), kh_ = tap_ / KS, kw_ = tap_ % KS;              \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                           \
+            bfr[set_][mt] = lds_frag(sA + (boff_) + aoff[mt] + ((2 * kc_) * C::PLANE_A + kh_ * C::HWP + kw_) * 16); \
+        _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                                                       \
+            afr[set_][nt] = lds_frag(sW + (boff_) + woff + ((2 * kc_) * C::PLANE_W + tap_ * BN + nt * 32) * 16);    \
     }
-    ISSUE_LOADS(0);
-    if constexpr (DB) {
+#define COMPUTE_CHUNK(boff_)                                                                                       \
+    LOAD_FRAGS(boff_, 0, 0)                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    _Pragma("unroll") for (int st = 0; st < NSTEPS; ++st) {                                                        \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                           \
+            _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                                                   \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][nt], bfr[st & 1][mt], acc[mt][nt], 0, 0, 0); \
+        if (st + 1 < NSTEPS) LOAD_FRAGS(boff_, st + 1, (st + 1) & 1)                                               \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2 + C::NT; ++q_) {                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA of this step ... */                     \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* ... then one fragment read of the next step */   \
+        }                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }
+    if constexpr (PP) {
+        // Ping-pong: group g owns the chunks c == g (mod 2) and its own LDS buffer.  In half-period k the group k&1 issues the
+        // loads of its next chunk and runs the MFMAs of chunk k, while the other group writes its already-arrived chunk k+1 to
+        // LDS and then parks at the barrier: on every SIMD exactly one of its two waves is in an MFMA phase at any time, so
+        // the matrix pipe never sees two load phases (or two MFMA phases) collide the way two free-running workgroups do.
+        if (grp == 0) { ISSUE_LOADS(0); WRITE_LDS(0); if (nchunks > 2) ISSUE_LOADS(2); }
+        else if (nchunks > 1) ISSUE_LOADS(1);
+        __syncthreads();
+        for (int k = 0; k < nchunks; ++k) {
+            if ((k & 1) == grp) {
+                COMPUTE_CHUNK(0)
+            } else if (k + 1 < nchunks) {
+                WRITE_LDS(0);
+                if (k + 3 < nchunks) ISSUE_LOADS(k + 3);
+            }
+            __syncthreads();
+        }
+    } else if constexpr (DB) {
+        ISSUE_LOADS(0);
         // double-buffered LDS, ONE barrier per chunk: loads of chunk c+1 fly under the MFMAs of chunk c and are written to
         // the other buffer afterwards; the barrier both publishes that buffer and retires every read of the current one.
         WRITE_LDS(0);
@@ -168,6 +205,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
             __syncthreads();
         }
     } else {
+        ISSUE_LOADS(0);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             __syncthreads();
             WRITE_LDS(0);
@@ -177,6 +215,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         }
     }
 #undef COMPUTE_CHUNK
+#undef LOAD_FRAGS
 
     // ---------------- epilogue: bias + residual + act -> bf16 -> LDS stage -> coalesced store ----------------
     // All bias / residual loads are issued back to back BEFORE the barrier (one latency, not one per quad), the
@@ -190,7 +229,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         for (int g = 0; g < 4; ++g) bias_r[nt][g] = *reinterpret_cast<const float4*>(bptr + nt * 32 + 8 * g + 4 * h);
     uint2 res_r[2][C::NT][4];
     const bool has_res = p.res != nullptr;
-    if (has_res) {
+    if (has_res && grp == 0) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int ty = wave * 2 + mt, tx = r;
@@ -209,7 +248,28 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         }
     }
     __syncthreads();
-    unsigned char* stage = smem;
+    unsigned char* stage = smem + C::XCHG_BYTES;
+    if constexpr (PP) {  // sum the two groups' partial accumulators (even chunks + odd chunks) through LDS, lane-linear layout
+        float* xch = reinterpret_cast<float*>(smem) + (size_t)(wave * 64 + lane);
+        if (grp == 1) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xch[((mt * C::NT + nt) * 16 + j) * 256] = acc[mt][nt][j];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[mt][nt][j] += xch[((mt * C::NT + nt) * 16 + j) * 256];
+        }
+    }
+    if (grp == 0) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -248,8 +308,10 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
                 *reinterpret_cast<uint2*>(stage + tp * C::STAGE_PITCH + cn * 2) = o;
             }
     }
+    }  // grp == 0
     __syncthreads();
     if (p.out_mode == OUT_CONVT && p.fuse_w != nullptr) {
+        if (grp != 0) return;
         // Fused DBHead tail on the matrix cores: D2[q2][pixel] = W3[q2][c] * act[c][pixel] (K = 64, rows >= 4 of W3 are zero).
         // B fragments come straight from the staged bf16 tile (row pitch 144 B: conflict-free b128 reads), A fragments from the
         // 2 KB pre-packed weight image [kstep][half][32][8]; lanes with h == 0 end up with the 4 outputs of their pixel.
@@ -283,6 +345,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     for (int k = 0; k < C::CPP; ++k) {
         const int i = tid + NTHR * k;
         const int tp = i / C::CPP, ch = i - tp * C::CPP;
+        if (tp >= GTHR) continue;
         const int ty = tp / TW, tx = tp - ty * TW;
         const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
         const int co = ntile * BN + ch * 8;
@@ -363,7 +426,8 @@ bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cf
     if (ks == 3 && stride == 2 && cfg->bn == 128 && cfg->ck == 32) cfg->bn = 64;  // halo tile is 4x larger: keep LDS < 160 KB
     // The 8-wave / 16x32-tile / double-buffered-LDS variant (one workgroup per CU, one barrier per chunk) measured SLOWER
     // than two independent 4-wave workgroups per CU (572 vs 601 TFLOP/s over DBNet): it stays available for experiments.
-    if (const char* e = getenv("LUMINA_CONV_NW")) { if (atoi(e) == 8 && ks == 3 && stride == 1 && cfg->bn == 64 && cfg->ck == 32 && cin >= 64) cfg->nw = 8; }
+    if (const char* e = getenv("LUMINA_CONV_CK3")) { if (ks == 3 && stride == 1 && cfg->bn == 64 && cin >= atoi(e)) cfg->ck = 16; }
+    if (const char* e = getenv("LUMINA_CONV_NW")) { if (atoi(e) >= 8 && ks == 3 && stride == 1 && cfg->bn == 64 && cfg->ck == 32 && cin >= 64) cfg->nw = atoi(e); }
     return true;
 }
 
@@ -384,7 +448,12 @@ hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t strea
         if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 32) return launch_t<3, 1, 64, 32, 32, 8, 1>(p, stream);
         return hipErrorInvalidValue;
     }
-    DISPATCH(3, 1, 32, 32) DISPATCH(3, 1, 64, 32) DISPATCH(3, 1, 128, 32)
+    if (cfg.nw == 9) {  // ping-pong variant: 8 waves in two role-alternating groups on one 8x32 tile
+        p.tiles_y = ceil_div(p.Ho, 8);
+        if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 32) return launch_t<3, 1, 64, 32, 32, 8, 2>(p, stream);
+        return hipErrorInvalidValue;
+    }
+    DISPATCH(3, 1, 32, 32) DISPATCH(3, 1, 64, 32) DISPATCH(3, 1, 128, 32) DISPATCH(3, 1, 64, 16)
     DISPATCH(3, 2, 32, 32) DISPATCH(3, 2, 64, 32)
     DISPATCH(1, 1, 32, 32) DISPATCH(1, 1, 64, 32) DISPATCH(1, 1, 128, 32)
     DISPATCH(1, 1, 32, 16) DISPATCH(1, 1, 64, 16) DISPATCH(1, 1, 128, 16)
