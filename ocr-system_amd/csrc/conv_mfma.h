@@ -28,6 +28,7 @@ struct ConvParams {
     // [N, 4*Ho, 4*Wo] and the intermediate 64-channel tensor is never written.
     const bf16_t* fuse_w;
     float fuse_b;
+    int dbg_skip;   // timing experiments only (LUMINA_CONV_DBG): 1 skip weight reloads, 2 skip halo reloads, 4 skip MFMAs (wrong results)
     int pix_limit;  // flat-GEMM mode (1x1): pixels >= pix_limit of an image are neither read nor written (0 = off)
 };
 
@@ -44,3 +45,7 @@ void pack_conv_weights(const bf16_t* ohwi, int cout_gemm, int ks, int cin, int b
 bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cfg);
 hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t stream);
 const char* conv_kernel_name(const ConvKernelCfg& cfg);
+
+// A-stationary 1x1 / GEMM kernel (conv1x1.hip): same packed weights as conv_mfma with bn == 64.
+bool conv1x1_supported(const ConvKernelCfg& cfg, const ConvParams& p);
+hipError_t conv1x1_launch(ConvParams p, long long total_px, hipStream_t stream);

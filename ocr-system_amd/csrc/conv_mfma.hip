@@ -107,16 +107,17 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
 #define ISSUE_LOADS(chunk_)                                                                          \
     {                                                                                                \
         const bf16_t* xa = ximg + (chunk_) * CK;                                                     \
+        const bool skipa_ = (p.dbg_skip & 2) && (chunk_) > 0, skipw_ = (p.dbg_skip & 1) && (chunk_) > 0; \
         _Pragma("unroll") for (int it = 0; it < C::AIT; ++it) {                                      \
             uint4 t_ = make_uint4(0, 0, 0, 0);                                                       \
-            if (a_goff[it] >= 0) t_ = *reinterpret_cast<const uint4*>(xa + a_goff[it]);              \
+            if (a_goff[it] >= 0 && !skipa_) t_ = *reinterpret_cast<const uint4*>(xa + a_goff[it]);   \
             a_reg[it] = t_;                                                                          \
         }                                                                                            \
         const uint4* wsrc = reinterpret_cast<const uint4*>(wbase + (size_t)(chunk_) * C::W_ITEMS * 8); \
         _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
             const int i = gtid + GTHR * it;                                                          \
             uint4 t_ = make_uint4(0, 0, 0, 0);                                                       \
-            if (C::W_ITEMS % GTHR == 0 || i < C::W_ITEMS) t_ = wsrc[i];                              \
+            if ((C::W_ITEMS % GTHR == 0 || i < C::W_ITEMS) && !skipw_) t_ = wsrc[i];                 \
             w_reg[it] = t_;                                                                          \
         }                                                                                            \
     }
@@ -441,6 +442,8 @@ const char* conv_kernel_name(const ConvKernelCfg& c) {
     if (cfg.ks == KS_ && cfg.stride == S_ && cfg.bn == BN_ && cfg.ck == CK_) return launch_t<KS_, S_, BN_, CK_, 32>(p, stream);
 
 hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t stream) {
+    static const int dbg = getenv("LUMINA_CONV_DBG") ? atoi(getenv("LUMINA_CONV_DBG")) : 0;
+    p.dbg_skip = dbg;
     p.tiles_x = ceil_div(p.Wo, 32);
     p.tiles_y = ceil_div(p.Ho, cfg.nw * 2);
     p.n_tiles = ceil_div(p.Cout, cfg.bn);

@@ -2,6 +2,7 @@
 // (CRNN-MobileNetV3) layer schedules.  Layer names/shapes mirror lumina_ocr/arch.py.
 #include "engine.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #include "ops.h"
@@ -219,7 +220,11 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, st));
     }
-    hipError_t e = conv_launch(L.cfg, p, st);
+    // conv1x1.hip (A-stationary, all channel tiles in one workgroup) measured SLOWER than one workgroup per channel tile
+    // on every DBNet 1x1 layer (fpn.in2 0.80 vs 0.68 ms / 16 pages): it is an opt-in experiment, not the default.
+    static const bool want1x1 = getenv("LUMINA_CONV1X1") != nullptr;
+    const bool use1x1 = want1x1 && conv1x1_supported(L.cfg, p);
+    hipError_t e = use1x1 ? conv1x1_launch(p, flat ? (long long)p.pix_limit : (long long)p.N * p.H * p.W, st) : conv_launch(L.cfg, p, st);
     if (e != hipSuccess) return locr_fail(eng, L.name.c_str(), hipGetErrorString(e));
     if (eng->time_convs) {
         HIPCHK(hipEventRecord(e1, st));
@@ -227,7 +232,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         const double px = flat ? (double)p.pix_limit : (double)p.N * p.Ho * p.Wo;
         eng->conv_flops.push_back(2.0 * px * L.ks * L.ks * L.cin * L.cout);
         eng->conv_names.push_back(L.name);
-        eng->conv_kernels.push_back(conv_kernel_name(L.cfg));
+        eng->conv_kernels.push_back(use1x1 ? "conv1x1_astat<bn64>" : conv_kernel_name(L.cfg));
     }
     return 0;
 }
@@ -443,10 +448,10 @@ int eng_load_rec(lumina_ocr* eng, const void* blob, size_t n) {
         auto w = m.find("ctc.fc.w"), b = m.find("ctc.fc.b");
         if (w == m.end() || b == m.end() || w->second.dims[1] != 2 * Hh) return locr_fail(eng, "ctc.fc", "missing/shape");
         const int C = w->second.dims[0];
-        eng->num_classes = C; eng->ctc_ntiles = (C + 127) / 128;
+        eng->num_classes = C; eng->ctc_ntiles = (C + 63) / 64;
         std::vector<bf16_t> packed(ctc_packed_weight_elems(C, 2 * Hh));
         pack_ctc_weights(reinterpret_cast<const bf16_t*>(w->second.data), C, 2 * Hh, packed.data());
-        std::vector<float> bias((size_t)eng->ctc_ntiles * 128, -1.0e30f);
+        std::vector<float> bias((size_t)eng->ctc_ntiles * 64, -1.0e30f);
         memcpy(bias.data(), b->second.data, sizeof(float) * C);
         eng->ctc_wpk = static_cast<bf16_t*>(dev_upload(eng, packed.data(), packed.size() * sizeof(bf16_t)));
         eng->ctc_bias = static_cast<float*>(dev_upload(eng, bias.data(), bias.size() * sizeof(float)));

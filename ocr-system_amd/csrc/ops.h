@@ -21,11 +21,11 @@ hipError_t se_scale_launch(const bf16_t* x, const bf16_t* gate, bf16_t* y, int N
 hipError_t lstm_recurrent_launch(const bf16_t* xproj, const bf16_t* whh, bf16_t* out, int N, int T, hipStream_t st);
 
 // CTC head: logits = seq[M][K] * W^T[K][C] + b, never materialised; per row -> argmax index + softmax max-prob.
-// wpk: weights packed [ntile][kchunk][plane][128 rows][8]; partial buffers sized M * ntiles.
+// wpk: weights packed [ntile of 64 classes][plane][64 rows][8] (pack_ctc_weights).
 struct CtcFcParams {
     const bf16_t* seq;  // [M][K], K % 32 == 0
     const bf16_t* wpk;
-    const float* bias;  // [ntiles*128], padded entries = -1e30 (never win)
+    const float* bias;  // [ntiles*64], padded entries = -1e30 (never win)
     float* part_max; int* part_idx; float* part_sum;  // [M][ntiles]
     int* out_idx; float* out_prob;                    // [M]
     int M, K, C, ntiles;

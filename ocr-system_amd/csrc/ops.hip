@@ -245,13 +245,14 @@ __global__ __launch_bounds__(192) void lstm_kernel(const bf16_t* xproj, const bf
 }
 
 // ------------------------------------------------------------------ CTC head: fused FC + argmax + softmax-max
-// A-stationary MFMA GEMM: the block keeps its 256 sequence rows (K <= 192) in LDS and streams all
-// 128-class weight tiles through a second LDS region; running (max, argmax, sum-exp) stay in registers,
+// A-stationary MFMA GEMM: the block keeps its 128 sequence rows (K <= 192) in LDS and streams all
+// 64-class weight tiles through a second LDS region; running (max, argmax, sum-exp) stay in registers,
 // the [M, C] logits never exist in memory.
-constexpr int CT_ROWS = 256, CT_BN = 128, CT_KMAX = 192;
+constexpr int CT_MT = 1, CT_NT = 2;  // per wave: CT_MT x 32 rows, CT_NT x 32 classes per weight tile (2 workgroups per CU)
+constexpr int CT_ROWS = 4 * 32 * CT_MT, CT_BN = 32 * CT_NT, CT_KMAX = 192, CT_WIT = CT_BN * (CT_KMAX / 8) / 256;
 constexpr int CT_PLANE_A = CT_ROWS + 4;  // entries, == 4 (mod 16)
 
-__global__ __launch_bounds__(256, 1) void ctc_fc_argmax_kernel(const CtcFcParams p) {
+__global__ __launch_bounds__(256, 2) void ctc_fc_argmax_kernel(const CtcFcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int npl = p.K >> 3;
     unsigned char* sA = smem;
@@ -266,63 +267,63 @@ __global__ __launch_bounds__(256, 1) void ctc_fc_argmax_kernel(const CtcFcParams
         *reinterpret_cast<uint4*>(sA + ((size_t)c * CT_PLANE_A + row) * 16) = v;
     }
     const int w_items = CT_BN * npl;           // 16-byte items per weight tile (<= 3072)
-    const int wit = (w_items + 255) / 256;     // <= 12
-    uint4 wreg[12];
+    const int wit = (w_items + 255) / 256;     // <= CT_WIT
+    uint4 wreg[CT_WIT];
 #define CTC_LOAD_W(tile_)                                                                              \
     {                                                                                                  \
         const uint4* src = reinterpret_cast<const uint4*>(p.wpk + (size_t)(tile_) * w_items * 8);      \
-        _Pragma("unroll") for (int it = 0; it < 12; ++it) {                                            \
+        _Pragma("unroll") for (int it = 0; it < CT_WIT; ++it) {                                            \
             const int i = tid + 256 * it;                                                              \
             uint4 t_ = make_uint4(0, 0, 0, 0);                                                         \
             if (it < wit && i < w_items) t_ = src[i];                                                  \
             wreg[it] = t_;                                                                             \
         }                                                                                              \
     }
-    float run_m[2], run_s[2];
-    int run_i[2];
+    float run_m[CT_MT], run_s[CT_MT];
+    int run_i[CT_MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) { run_m[mt] = -3.0e38f; run_s[mt] = 0.f; run_i[mt] = 0; }
+    for (int mt = 0; mt < CT_MT; ++mt) { run_m[mt] = -3.0e38f; run_s[mt] = 0.f; run_i[mt] = 0; }
 
     CTC_LOAD_W(0);
     const int ksteps = p.K >> 4;
     for (int tile = 0; tile < p.ntiles; ++tile) {
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 12; ++it) {
+        for (int it = 0; it < CT_WIT; ++it) {
             const int i = tid + 256 * it;
             if (it < wit && i < w_items) *reinterpret_cast<uint4*>(sW + (size_t)i * 16) = wreg[it];
         }
         __syncthreads();
         if (tile + 1 < p.ntiles) CTC_LOAD_W(tile + 1);
-        f32x16_t acc[2][4];
+        f32x16_t acc[CT_MT][CT_NT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < CT_MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < CT_NT; ++nt)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
         for (int kc = 0; kc < ksteps; ++kc) {
-            bf16x8_t bfr[2], afr[4];
+            bf16x8_t bfr[CT_MT], afr[CT_NT];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                bfr[mt] = *reinterpret_cast<const bf16x8_t*>(sA + ((size_t)(2 * kc + h) * CT_PLANE_A + wave * 64 + mt * 32 + r) * 16);
+            for (int mt = 0; mt < CT_MT; ++mt)
+                bfr[mt] = *reinterpret_cast<const bf16x8_t*>(sA + ((size_t)(2 * kc + h) * CT_PLANE_A + wave * (32 * CT_MT) + mt * 32 + r) * 16);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < CT_NT; ++nt)
                 afr[nt] = *reinterpret_cast<const bf16x8_t*>(sW + ((size_t)(2 * kc + h) * CT_BN + nt * 32 + r) * 16);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < CT_MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < CT_NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[nt], bfr[mt], acc[mt][nt], 0, 0, 0);
         }
         // per-tile reduction over this lane's 64 classes, then the partner half-wave, then the running state
         const float* bt = p.bias + tile * CT_BN;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < CT_MT; ++mt) {
             float tm = -3.0e38f;
             int ti = 0;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < CT_NT; ++nt)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int cls = nt * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void ctc_fc_argmax_kernel(const CtcFcParams
             if (om > tm || (om == tm && oi < ti)) { tm = om; ti = oi; }
             float ts = 0.f;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < CT_NT; ++nt)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) ts += __builtin_amdgcn_exp2f((acc[mt][nt][j] - tm) * 1.4426950408889634f);
             ts += __shfl_xor(ts, 32);
@@ -350,8 +351,8 @@ __global__ __launch_bounds__(256, 1) void ctc_fc_argmax_kernel(const CtcFcParams
     }
     if (h == 0) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int row = row0 + wave * 64 + mt * 32 + r;
+        for (int mt = 0; mt < CT_MT; ++mt) {
+            const int row = row0 + wave * (32 * CT_MT) + mt * 32 + r;
             if (row < p.M) { p.out_idx[row] = run_i[mt]; p.out_prob[row] = 1.f / run_s[mt]; }
         }
     }
