@@ -27,12 +27,12 @@
 
 namespace {
 
-template <int KS, int S, int BN, int CK, int TW, int NW = 4, int DB = 0>
+template <int KS, int S, int BN, int CK, int TW, int NW = 4, int DB = 0, int MT = 2>
 struct Cfg {
     static constexpr int NTHR = NW * 64;
     static constexpr bool PP = (DB == 2);           // ping-pong: two 4-wave groups alternate compute / stage roles
     static constexpr int GTHR = PP ? 256 : NTHR;    // threads that cooperate on one LDS buffer
-    static constexpr int TH = GTHR / TW;
+    static constexpr int TH = (GTHR / 64) * MT;     // TW == 32: every wave owns MT pixel rows (MT 32-pixel MFMA column tiles)
     static constexpr int PAD = (KS == 3) ? 1 : 0;
     static constexpr int HH = (TH - 1) * S + KS;
     static constexpr int HW = (TW - 1) * S + KS;
@@ -48,9 +48,9 @@ struct Cfg {
     static constexpr int A_BYTES = PLANE_A * NPL * 16;
     static constexpr int W_BYTES = PLANE_W * NPL * 16;
     static constexpr int STAGE_PITCH = BN * 2 + 16;
-    static constexpr int STAGE_BYTES = GTHR * STAGE_PITCH;
+    static constexpr int STAGE_BYTES = TH * TW * STAGE_PITCH;
     static constexpr int BUF_BYTES = A_BYTES + W_BYTES;
-    static constexpr int XCHG_BYTES = PP ? 256 * 2 * NT * 16 * 4 : 0;  // fp32 accumulators of the second group
+    static constexpr int XCHG_BYTES = PP ? 256 * MT * NT * 16 * 4 : 0;  // fp32 accumulators of the second group
     static constexpr int LDS_BYTES = (BUF_BYTES * (DB ? 2 : 1)) > (XCHG_BYTES + STAGE_BYTES) ? (BUF_BYTES * (DB ? 2 : 1)) : (XCHG_BYTES + STAGE_BYTES);
     static constexpr int A_ITEMS = HH * HW * NPL;
     static constexpr int AIT = (A_ITEMS + GTHR - 1) / GTHR;
@@ -61,9 +61,9 @@ struct Cfg {
 
 __device__ __forceinline__ bf16x8_t lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 
-template <int KS, int S, int BN, int CK, int TW, int NW, int DB>
+template <int KS, int S, int BN, int CK, int TW, int NW, int DB, int MT>
 __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void conv_mfma_kernel(const ConvParams p) {
-    using C = Cfg<KS, S, BN, CK, TW, NW, DB>;
+    using C = Cfg<KS, S, BN, CK, TW, NW, DB, MT>;
     constexpr int NTHR = C::NTHR, GTHR = C::GTHR;
     constexpr bool PP = C::PP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -131,19 +131,19 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         }                                                                                            \
     }
 
-    f32x16_t acc[2][C::NT];
+    f32x16_t acc[MT][C::NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
 
     // fragment read bases (bytes)
-    int aoff[2];
+    int aoff[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int ty = wave * 2 + mt, tx = r;  // TW == 32
+    for (int mt = 0; mt < MT; ++mt) {
+        const int ty = wave * MT + mt, tx = r;  // TW == 32
         aoff[mt] = (h * C::PLANE_A + (ty * S) * C::HWP + tx * S) * 16;
     }
     const int woff = (h * C::PLANE_W + r) * 16;
@@ -152,11 +152,11 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     // in flight while the 2*NT MFMAs of step s issue (hipcc otherwise places every ds_read right in front of its MFMA and the
     // wave idles for the LDS latency once per step).
     constexpr int NSTEPS = C::TAPS * (CK / 16);
-    bf16x8_t bfr[2][2], afr[2][C::NT];
+    bf16x8_t bfr[2][MT], afr[2][C::NT];
 #define LOAD_FRAGS(boff_, st_, set_)                                                                               \
     {                                                                                                              \
         const int tap_ = (st_) / (CK / 16), kc_ = (st_) % (CK / 16), kh_ = tap_ / KS, kw_ = tap_ % KS;              \
-        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                           \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
             bfr[set_][mt] = lds_frag(sA + (boff_) + aoff[mt] + ((2 * kc_) * C::PLANE_A + kh_ * C::HWP + kw_) * 16); \
         _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                                                       \
             afr[set_][nt] = lds_frag(sW + (boff_) + woff + ((2 * kc_) * C::PLANE_W + tap_ * BN + nt * 32) * 16);    \
@@ -165,13 +165,13 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     LOAD_FRAGS(boff_, 0, 0)                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     _Pragma("unroll") for (int st = 0; st < NSTEPS; ++st) {                                                        \
-        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                           \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
             _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                                                   \
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][nt], bfr[st & 1][mt], acc[mt][nt], 0, 0, 0); \
         if (st + 1 < NSTEPS) LOAD_FRAGS(boff_, st + 1, (st + 1) & 1)                                               \
-        _Pragma("unroll") for (int q_ = 0; q_ < 2 + C::NT; ++q_) {                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < MT * C::NT; ++q_) {                                                \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA of this step ... */                     \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* ... then one fragment read of the next step */   \
+            if (q_ < MT + C::NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* ... one read of the next */ \
         }                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
     }
@@ -228,12 +228,12 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) bias_r[nt][g] = *reinterpret_cast<const float4*>(bptr + nt * 32 + 8 * g + 4 * h);
-    uint2 res_r[2][C::NT][4];
+    uint2 res_r[MT][C::NT][4];
     const bool has_res = p.res != nullptr;
     if (has_res && grp == 0) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int ty = wave * 2 + mt, tx = r;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int ty = wave * MT + mt, tx = r;
             const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
             const bool pvalid = oy < p.Ho && ox < p.Wo && (p.pix_limit == 0 || oy * p.Wo + ox < p.pix_limit);
             const bf16_t* rrow = p.res + (((size_t)n_img * p.res_h + (oy >> p.res_shift)) * p.res_w + (ox >> p.res_shift)) * p.res_cstride + ntile * BN;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         float* xch = reinterpret_cast<float*>(smem) + (size_t)(wave * 64 + lane);
         if (grp == 1) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         __syncthreads();
         if (grp == 0) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     }
     if (grp == 0) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
                 }
             }
 #define FOR_ALL_ACC(expr)                                                          \
-    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                               \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                               \
         _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                       \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) { const float v = acc[mt][nt][j]; acc[mt][nt][j] = (expr); }
     if (p.act == ACT_RELU) { FOR_ALL_ACC(fmaxf(v, 0.f)) }
@@ -296,8 +296,8 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     else if (p.act == ACT_HSIGMOID) { FOR_ALL_ACC(fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f)) }
 #undef FOR_ALL_ACC
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int tp = (wave * 2 + mt) * TW + r;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int tp = (wave * MT + mt) * TW + r;
 #pragma unroll
         for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
@@ -319,18 +319,18 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         if constexpr (BN == 64) {
             const int q = ntile;  // convt_c == 64: one sub-pixel per cout tile
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 f32x16_t d2;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) d2[j] = 0.f;
-                const int tp = (wave * 2 + mt) * TW + r;
+                const int tp = (wave * MT + mt) * TW + r;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const bf16x8_t bfr = lds_frag(stage + tp * C::STAGE_PITCH + (ks * 16 + h * 8) * 2);
                     const bf16x8_t afr = *reinterpret_cast<const bf16x8_t*>(p.fuse_w + ((ks * 2 + h) * 32 + r) * 8);
                     d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, d2, 0, 0, 0);
                 }
-                const int ty = wave * 2 + mt, tx = r;
+                const int ty = wave * MT + mt, tx = r;
                 const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
                 if (h == 0 && oy < p.Ho && ox < p.Wo) {
                     const int yy = 4 * oy + 2 * (q >> 1), xx = 4 * ox + 2 * (q & 1);
@@ -343,10 +343,10 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         return;
     }
 #pragma unroll
-    for (int k = 0; k < C::CPP; ++k) {
+    for (int k = 0; k < (C::TH * TW * C::CPP + NTHR - 1) / NTHR; ++k) {
         const int i = tid + NTHR * k;
         const int tp = i / C::CPP, ch = i - tp * C::CPP;
-        if (tp >= GTHR) continue;
+        if (tp >= C::TH * TW) continue;
         const int ty = tp / TW, tx = tp - ty * TW;
         const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
         const int co = ntile * BN + ch * 8;
@@ -378,10 +378,10 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     }
 }
 
-template <int KS, int S, int BN, int CK, int TW, int NW = 4, int DB = 0>
+template <int KS, int S, int BN, int CK, int TW, int NW = 4, int DB = 0, int MT = 2>
 hipError_t launch_t(const ConvParams& p, hipStream_t stream) {
-    using C = Cfg<KS, S, BN, CK, TW, NW, DB>;
-    auto kern = conv_mfma_kernel<KS, S, BN, CK, TW, NW, DB>;
+    using C = Cfg<KS, S, BN, CK, TW, NW, DB, MT>;
+    auto kern = conv_mfma_kernel<KS, S, BN, CK, TW, NW, DB, MT>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -428,7 +428,10 @@ bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cf
     // The 8-wave / 16x32-tile / double-buffered-LDS variant (one workgroup per CU, one barrier per chunk) measured SLOWER
     // than two independent 4-wave workgroups per CU (572 vs 601 TFLOP/s over DBNet): it stays available for experiments.
     if (const char* e = getenv("LUMINA_CONV_CK3")) { if (ks == 3 && stride == 1 && cfg->bn == 64 && cin >= atoi(e)) cfg->ck = 16; }
-    if (const char* e = getenv("LUMINA_CONV_NW")) { if (atoi(e) >= 8 && ks == 3 && stride == 1 && cfg->bn == 64 && cfg->ck == 32 && cin >= 64) cfg->nw = atoi(e); }
+    if (const char* e = getenv("LUMINA_CONV_NW")) {
+        if (atoi(e) >= 8 && ks == 3 && stride == 1 && cfg->bn == 64 && cfg->ck == 32 && cin >= 64) cfg->nw = atoi(e);
+        if (atoi(e) == 5 && ks == 3 && stride == 1 && cfg->bn == 64 && cin >= 64) { cfg->nw = 5; cfg->ck = 16; }
+    }
     return true;
 }
 
@@ -449,6 +452,11 @@ hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t strea
     p.n_tiles = ceil_div(p.Cout, cfg.bn);
     if (cfg.nw == 8) {  // 512-thread, double-buffered variant (3x3/s1, multi-chunk layers)
         if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 32) return launch_t<3, 1, 64, 32, 32, 8, 1>(p, stream);
+        return hipErrorInvalidValue;
+    }
+    if (cfg.nw == 5) {  // 4 waves, 4 pixel rows per wave: 16x32-pixel tile, 4x2 MFMA register tile, CK = 16
+        p.tiles_y = ceil_div(p.Ho, 16);
+        if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16) return launch_t<3, 1, 64, 16, 32, 4, 0, 4>(p, stream);
         return hipErrorInvalidValue;
     }
     if (cfg.nw == 9) {  // ping-pong variant: 8 waves in two role-alternating groups on one 8x32 tile

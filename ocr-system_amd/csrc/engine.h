@@ -21,6 +21,9 @@ struct ConvLayer {
     int convt_c = 0;
     ConvKernelCfg cfg{};
     bf16_t* wpk = nullptr;  // device
+    // second packing for the 16x32-tile / 4x2-register-tile kernel (3x3, stride 1, >= 64 input channels): picked per launch
+    // when the grid is large enough to fill the chip with the bigger tiles
+    ConvKernelCfg cfg_big{}; bf16_t* wpk_big = nullptr;
     bf16_t* fuse_w = nullptr; float fuse_b = 0.f;  // optional fused DBHead tail (see ConvParams)
     float* bias = nullptr;  // device, n_tiles*BN
 };

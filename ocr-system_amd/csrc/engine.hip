@@ -112,6 +112,12 @@ static bool make_conv(lumina_ocr* eng, const std::map<std::string, HostBlobTenso
     std::vector<bf16_t> packed(conv_packed_weight_elems(cout_p, ks, cin_p, L->cfg.bn));
     pack_conv_weights(padded.data(), cout_p, ks, cin_p, L->cfg.bn, L->cfg.ck, packed.data());
     L->wpk = static_cast<bf16_t*>(dev_upload(eng, packed.data(), packed.size() * sizeof(bf16_t)));
+    if (ks == 3 && stride == 1 && L->cfg.bn == 64 && cin_p >= 64 && L->cfg.nw == 4) {
+        L->cfg_big = L->cfg; L->cfg_big.nw = 5; L->cfg_big.ck = 16;
+        std::vector<bf16_t> packed2(conv_packed_weight_elems(cout_p, ks, cin_p, 64));
+        pack_conv_weights(padded.data(), cout_p, ks, cin_p, 64, 16, packed2.data());
+        L->wpk_big = static_cast<bf16_t*>(dev_upload(eng, packed2.data(), packed2.size() * sizeof(bf16_t)));
+    }
     const int ntiles = (cout_p + L->cfg.bn - 1) / L->cfg.bn;
     std::vector<float> bias((size_t)ntiles * L->cfg.bn, 0.f);
     const float* bs = reinterpret_cast<const float*>(b->data);
@@ -223,8 +229,14 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     // conv1x1.hip (A-stationary, all channel tiles in one workgroup) measured SLOWER than one workgroup per channel tile
     // on every DBNet 1x1 layer (fpn.in2 0.80 vs 0.68 ms / 16 pages): it is an opt-in experiment, not the default.
     static const bool want1x1 = getenv("LUMINA_CONV1X1") != nullptr;
+    static const bool no_big = getenv("LUMINA_CONV_NO_BIG") != nullptr;
     const bool use1x1 = want1x1 && conv1x1_supported(L.cfg, p);
-    hipError_t e = use1x1 ? conv1x1_launch(p, flat ? (long long)p.pix_limit : (long long)p.N * p.H * p.W, st) : conv_launch(L.cfg, p, st);
+    // 16x32 tiles (less LDS and L2 traffic per MFMA) once they still give >= 2 workgroups per CU on all 256 CUs twice over
+    const long long big_blocks = (long long)p.N * ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32) * ((L.cout + 63) / 64);
+    const bool use_big = !no_big && !flat && L.wpk_big != nullptr && big_blocks >= 1024;
+    ConvKernelCfg cfg = L.cfg;
+    if (use_big) { cfg = L.cfg_big; p.wpk = L.wpk_big; }
+    hipError_t e = use1x1 ? conv1x1_launch(p, flat ? (long long)p.pix_limit : (long long)p.N * p.H * p.W, st) : conv_launch(cfg, p, st);
     if (e != hipSuccess) return locr_fail(eng, L.name.c_str(), hipGetErrorString(e));
     if (eng->time_convs) {
         HIPCHK(hipEventRecord(e1, st));
@@ -232,7 +244,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         const double px = flat ? (double)p.pix_limit : (double)p.N * p.Ho * p.Wo;
         eng->conv_flops.push_back(2.0 * px * L.ks * L.ks * L.cin * L.cout);
         eng->conv_names.push_back(L.name);
-        eng->conv_kernels.push_back(use1x1 ? "conv1x1_astat<bn64>" : conv_kernel_name(L.cfg));
+        eng->conv_kernels.push_back(use1x1 ? "conv1x1_astat<bn64>" : conv_kernel_name(cfg));
     }
     return 0;
 }
