@@ -34,6 +34,7 @@ class OcrPipeline:
     def __init__(self, engine: Engine, charset: Optional[List[str]] = None, max_dimension: int = 2000, post: Optional[dict] = None):
         self.eng = engine
         self.charset = charset or arch.ctc_charset(engine.num_classes or 6625)
+        self._codepoints = np.array([ord(c) for c in self.charset], dtype="<u4")   # class id -> code point (vectorised decode)
         self.max_dimension = max_dimension
         self.post = dict(arch.DEFAULT_POST if post is None else post)
 
@@ -66,11 +67,11 @@ class OcrPipeline:
         text, length, score = self.eng.ctc_decode(idx, prob)
         text_h, len_h, score_h = text.cpu().numpy(), length.cpu().numpy(), score.cpu().numpy()
         quads_h, det_h = quads.cpu().numpy(), det_sc.cpu().numpy()
-        cs = self.charset
+        cps = self._codepoints[np.maximum(text_h, 0)]          # [n, 80] uint32 code points; one utf-32 decode per line
         out, off = [], 0
         for p in range(b):
             c = int(counts_h[p])
-            texts = ["".join(cs[k] for k in text_h[i, : len_h[i]]) for i in range(off, off + c)]
+            texts = [cps[i, : len_h[i]].tobytes().decode("utf-32-le") for i in range(off, off + c)]
             out.append(PageDetections(quads_h[off:off + c], texts, score_h[off:off + c], det_h[off:off + c], w, h))
             off += c
         return out
