@@ -43,7 +43,7 @@ def make_pages(torch, n, seed, device):
     return pages
 
 
-def cpu_baseline(det_w, rec_w, charset, n_pages=1):
+def cpu_baseline(det_w, rec_w, charset, n_pages=6):
     """Oracle port of the same path on the host cores (torch-CPU fp32 convs + C post-process), bounded sample."""
     import numpy as np
     import torch
@@ -123,12 +123,25 @@ def main():
         elapsed = float(t.item())
     n_lines = sum(len(d["texts"]) if isinstance(d, dict) else len(d.texts) for d in dets)
 
-    # ---- roofline of the dominant kernel family, HIP events on the launch stream, one extra step ----
+    # ---- roofline: HIP events on the launch stream around every conv_mfma launch of one extra step ----
     eng.set_option("time_convs", 1)
     pipe.run(pages)
-    conv_ms, conv_flops, conv_launches = eng.conv_timing()
+    rows = eng.conv_timing_detail()          # (layer, kernel instantiation, ms, GFLOP, algorithmic MB) per launch
     eng.set_option("time_convs", 0)
-    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    by_kernel = {}
+    for _, kern, ms, gf, mb in rows:
+        a = by_kernel.setdefault(kern, [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += gf; a[3] += mb
+    dom = max(by_kernel, key=lambda k: by_kernel[k][1])
+    dn, dms, dgf, dmb = by_kernel[dom]
+    fam_ms = sum(a[1] for a in by_kernel.values()); fam_gf = sum(a[2] for a in by_kernel.values())
+    achieved = dgf / dms if dms > 0 else 0.0   # GFLOP/ms == TFLOP/s
+    traffic = None
+    try:  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/r01_pmc_hbm.json, 16-page det forward)
+        pmc = json.loads((ROOT / "profiles" / "r01_pmc_hbm.json").read_text())
+        traffic = pmc.get("bench_dominant_kernel", {}).get("hbm_bytes_per_launch")
+    except Exception:
+        pass
 
     if rank == 0:
         hp, wp = 2016, 1440
@@ -149,10 +162,14 @@ def main():
             "config": {"workload": "end-to-end det+rec, batch=64 A4@200DPI pages per GPU (BASELINE configs[3])",
                        "pages_per_gpu": args.pages, "global_batch": args.pages * world, "page_px": [A4_H, A4_W],
                        "det_input_px": [hp, wp], "lines_last_step": n_lines, "parallelism": "pages sharded dp%d, 1 all-gather/step" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (all instantiations, %d launches/step)" % conv_launches,
+            "roofline": {"bound": "mfma", "kernel": dom, "launches_per_step": dn, "avg_launch_us": round(dms / dn * 1e3, 1),
+                         "flop_per_launch": dgf / dn * 1e9, "algorithmic_bytes_per_launch": dmb / dn * 1e6,
                          "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
-                         "flops_per_step": conv_flops, "kernel_ms_per_step": round(conv_ms, 3)},
+                         "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "mean HBM bytes/launch of this kernel in a 16-page det forward (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm.json); bench launches cover 16-page sub-batches too",
+                         "family": {"kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": len(rows),
+                                    "ms_per_step": round(fam_ms, 3), "achieved": round(fam_gf / fam_ms, 2),
+                                    "frac": round(fam_gf / fam_ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}},
         }
         if not args.no_cpu_baseline:
             try:

@@ -182,7 +182,7 @@ int lumina_ocr_conv_timing(lumina_ocr_t* h, double* total_ms, double* total_flop
         (void)hipEventDestroy(h->conv_events[i].first); (void)hipEventDestroy(h->conv_events[i].second);
     }
     *total_ms = ms; *total_flops = fl; *launches = (int)h->conv_events.size();
-    h->conv_events.clear(); h->conv_flops.clear(); h->conv_names.clear(); h->conv_kernels.clear();
+    h->conv_events.clear(); h->conv_flops.clear(); h->conv_bytes.clear(); h->conv_names.clear(); h->conv_kernels.clear();
     return 0;
 }
 
@@ -270,11 +270,11 @@ int lumina_ocr_conv_timing_detail(lumina_ocr_t* h, char* buf, size_t cap) {
         float t = 0.f;
         (void)hipEventElapsedTime(&t, h->conv_events[i].first, h->conv_events[i].second);
         char line[256];
-        snprintf(line, sizeof(line), "%s %s %.4f %.4f\n", h->conv_names[i].c_str(), h->conv_kernels[i].c_str(), t, h->conv_flops[i] * 1e-9);
+        snprintf(line, sizeof(line), "%s %s %.4f %.4f %.4f\n", h->conv_names[i].c_str(), h->conv_kernels[i].c_str(), t, h->conv_flops[i] * 1e-9, h->conv_bytes[i] * 1e-6);
         out += line;
         (void)hipEventDestroy(h->conv_events[i].first); (void)hipEventDestroy(h->conv_events[i].second);
     }
-    h->conv_events.clear(); h->conv_flops.clear(); h->conv_names.clear(); h->conv_kernels.clear();
+    h->conv_events.clear(); h->conv_flops.clear(); h->conv_bytes.clear(); h->conv_names.clear(); h->conv_kernels.clear();
     snprintf(buf, cap, "%s", out.c_str());
     return 0;
 }

@@ -437,7 +437,8 @@ bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cf
 
 const char* conv_kernel_name(const ConvKernelCfg& c) {
     static thread_local char buf[64];
-    snprintf(buf, sizeof(buf), "conv_mfma<k%d,s%d,bn%d,ck%d,w%d>", c.ks, c.stride, c.bn, c.ck, c.nw);
+    const int nw = c.nw >= 8 ? 8 : 4, db = c.nw == 8 ? 1 : (c.nw == 9 ? 2 : 0), mt = c.nw == 5 ? 4 : 2;
+    snprintf(buf, sizeof(buf), "conv_mfma_kernel<%d,%d,%d,%d,32,%d,%d,%d>", c.ks, c.stride, c.bn, c.ck, nw, db, mt);  // as rocprofv3 prints it (modulo spaces)
     return buf;
 }
 

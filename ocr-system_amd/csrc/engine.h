@@ -66,7 +66,7 @@ struct lumina_ocr {
     // per-kernel event timing (bench roofline): accumulated conv-kernel time of the last det forward
     bool time_convs = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_events;
-    std::vector<double> conv_flops;
+    std::vector<double> conv_flops, conv_bytes;
     std::vector<std::string> conv_names, conv_kernels;
     // ---- pre-processing (resize / enhance) ----
     struct Coeffs { int ksize = 0; int* bounds = nullptr; int* kk = nullptr; };

@@ -243,6 +243,8 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         eng->conv_events.push_back({e0, e1});
         const double px = flat ? (double)p.pix_limit : (double)p.N * p.Ho * p.Wo;
         eng->conv_flops.push_back(2.0 * px * L.ks * L.ks * L.cin * L.cout);
+        // algorithmic HBM bytes: input once + output once (+ residual) + weights once
+        eng->conv_bytes.push_back(2.0 * ((double)x.elems() + px * (out_mode == OUT_CONVT && p.fuse_w ? 4.0 : (double)L.cout) * (out_mode == OUT_UPSAMPLE ? (double)(1 << (2 * up_shift)) : 1.0) + (res ? px * (double)L.cout / (double)(1 << (2 * res_shift)) : 0.0) + (double)L.ks * L.ks * L.cin * L.cout));
         eng->conv_names.push_back(L.name);
         eng->conv_kernels.push_back(use1x1 ? "conv1x1_astat<bn64>" : conv_kernel_name(cfg));
     }

@@ -254,8 +254,8 @@ class Engine:
         self._chk(self.lib.lumina_ocr_conv_timing_detail(self._h, buf, len(buf)))
         rows = []
         for line in buf.value.decode().splitlines():
-            name, kern, ms, gf = line.split()
-            rows.append((name, kern, float(ms), float(gf)))
+            name, kern, ms, gf, mb = line.split()
+            rows.append((name, kern, float(ms), float(gf), float(mb)))
         return rows
 
     # -- pre-processing on device (image_preprocessing.py:81-110, :132-158) -----------------

@@ -27,12 +27,12 @@ eng.det_forward(pages, out=prob)
 rows = eng.conv_timing_detail()
 eng.set_option("time_convs", 0)
 agg = {}
-for name, kern, ms, gf in rows:
-    a = agg.setdefault(name, [kern, 0.0, 0.0]); a[1] += ms; a[2] += gf
+for name, kern, ms, gf, mb in rows:
+    a = agg.setdefault(name, [kern, 0.0, 0.0, 0.0]); a[1] += ms; a[2] += gf; a[3] += mb
 tot = sum(a[1] for a in agg.values())
 lines.append("conv kernels total %.2f ms (event-timed, serialised), %.1f TFLOP/s" % (tot, sum(a[2] for a in agg.values()) / tot))
-for name, (kern, ms, gf) in agg.items():
-    lines.append("%-14s %-28s %8.3f ms %8.1f GFLOP %7.1f TFLOP/s" % (name, kern, ms, gf, gf / ms))
+for name, (kern, ms, gf, mb) in agg.items():
+    lines.append("%-14s %-30s %8.3f ms %8.1f GFLOP %7.1f TFLOP/s %8.1f MB %6.2f TB/s(alg)" % (name, kern, ms, gf, gf / ms, mb, mb / ms / 1e3))
 os.makedirs("gpurun_out", exist_ok=True)
 open("gpurun_out/perf_probe.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
