@@ -82,7 +82,7 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    distributed = world > 1
+    distributed = world > 1 or "RANK" in os.environ   # under torchrun the RCCL path runs even at world size 1
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
@@ -121,7 +121,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    n_lines = sum(len(d["texts"]) if isinstance(d, dict) else len(d.texts) for d in dets)
+    n_lines = int(dets.counts.sum()) if hasattr(dets, "counts") else sum(len(d.texts) for d in dets)
 
     # ---- roofline: HIP events on the launch stream around every conv_mfma launch of one extra step ----
     eng.set_option("time_convs", 1)

@@ -28,41 +28,67 @@ def encode_text(text: str, index_of: dict) -> List[int]:
 
 
 def pack_pages(pages: Sequence, capacity: int, index_of: dict) -> np.ndarray:
-    """pages: PageDetections-like (quads, texts, scores, det_scores) -> int32 [P, 1 + capacity, ROW]; row 0 col 0 = count."""
+    """pages: PageDetections-like (quads, texts, scores, det_scores[, text_ids, lens]) -> int32 [P, 1 + capacity, ROW];
+    row 0 col 0 = count.  With text_ids/lens present (the pipeline's own output) no per-character Python work happens."""
     buf = np.full((len(pages), 1 + capacity, ROW), -1, np.int32)
     for p, pg in enumerate(pages):
         n = min(len(pg.texts), capacity)
         buf[p, 0, 0] = n
-        if n:
-            buf[p, 1:1 + n, :8] = np.asarray(pg.quads[:n], np.int32)
-            buf[p, 1:1 + n, 8] = np.asarray(pg.scores[:n], np.float32).view(np.int32)
-            buf[p, 1:1 + n, 9] = np.asarray(pg.det_scores[:n], np.float32).view(np.int32)
+        if not n:
+            continue
+        buf[p, 1:1 + n, :8] = np.asarray(pg.quads[:n], np.int32)
+        buf[p, 1:1 + n, 8] = np.asarray(pg.scores[:n], np.float32).view(np.int32)
+        buf[p, 1:1 + n, 9] = np.asarray(pg.det_scores[:n], np.float32).view(np.int32)
+        ids = getattr(pg, "text_ids", None)
+        if ids is not None:
+            buf[p, 1:1 + n, 10] = np.asarray(pg.lens[:n], np.int32)
+            buf[p, 1:1 + n, 11:11 + REC_T] = np.asarray(ids[:n], np.int32)
+        else:
             for i in range(n):
-                ids = encode_text(pg.texts[i], index_of)
-                buf[p, 1 + i, 10] = len(ids)
-                buf[p, 1 + i, 11:11 + len(ids)] = ids
+                row = encode_text(pg.texts[i], index_of)
+                buf[p, 1 + i, 10] = len(row)
+                buf[p, 1 + i, 11:11 + len(row)] = row
     return buf
 
 
+class GatheredPages:
+    """All ranks' results in global page order; strings are decoded lazily (vectorised utf-32), boxes/scores are views."""
+
+    def __init__(self, buf: np.ndarray, charset: Sequence[str]):
+        self.buf = buf
+        self._cp = np.array([ord(c) for c in charset], dtype="<u4")
+
+    def __len__(self) -> int:
+        return self.buf.shape[0]
+
+    @property
+    def counts(self) -> np.ndarray:
+        return self.buf[:, 0, 0]
+
+    def page(self, p: int) -> dict:
+        n = int(self.buf[p, 0, 0])
+        rows = self.buf[p, 1:1 + n]
+        cps = self._cp[np.maximum(rows[:, 11:], 0)]
+        texts = [cps[i, : rows[i, 10]].tobytes().decode("utf-32-le") for i in range(n)]
+        return dict(quads=rows[:, :8].copy(), texts=texts, scores=rows[:, 8].copy().view(np.float32),
+                    det_scores=rows[:, 9].copy().view(np.float32))
+
+    def pages(self) -> List[dict]:
+        return [self.page(p) for p in range(len(self))]
+
+
 def unpack_pages(buf: np.ndarray, charset: Sequence[str]):
-    out = []
-    for p in range(buf.shape[0]):
-        n = int(buf[p, 0, 0])
-        rows = buf[p, 1:1 + n]
-        texts = ["".join(charset[k] for k in r[11:11 + r[10]]) for r in rows]
-        out.append(dict(quads=rows[:, :8].copy(), texts=texts, scores=rows[:, 8].copy().view(np.float32),
-                        det_scores=rows[:, 9].copy().view(np.float32)))
-    return out
+    return GatheredPages(buf, charset).pages()
 
 
 def all_gather_pages(local_pages: Sequence, charset: Sequence[str], device=None, pages_per_rank: int = 0):
-    """Gather every rank's per-page results; returns the list for ALL pages in global page order.
+    """Gather every rank's per-page results; returns a GatheredPages over ALL pages in global page order.
     Requires torch.distributed to be initialised; every rank must call it with the same pages_per_rank
     (ranks holding fewer pages are padded with empty pages)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
-    index_of = {ch: i for i, ch in enumerate(charset)}
+    index_of = None if all(getattr(p, "text_ids", None) is not None for p in local_pages) else {ch: i for i, ch in enumerate(charset)}
     ppr = pages_per_rank or len(local_pages)
     cap_t = torch.tensor([max([len(p.texts) for p in local_pages] + [1])], dtype=torch.int32, device=device)
     dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)          # scalar: common capacity
@@ -74,5 +100,4 @@ def all_gather_pages(local_pages: Sequence, charset: Sequence[str], device=None,
     lt = torch.from_numpy(local).to(device) if device is not None else torch.from_numpy(local)
     gathered = torch.empty((world * ppr, 1 + cap, ROW), dtype=torch.int32, device=lt.device)
     dist.all_gather_into_tensor(gathered, lt)             # the one data collective of the batch
-    g = gathered.cpu().numpy()
-    return unpack_pages(g, charset)
+    return GatheredPages(gathered.cpu().numpy(), charset)

@@ -25,6 +25,8 @@ class PageDetections:
     det_scores: np.ndarray     # float32 [n]  DB box score
     width: int = 0             # processed image size
     height: int = 0
+    text_ids: Optional[np.ndarray] = None   # int32 [n, 80] class ids (-1 padded): what travels in the multi-GPU gather
+    lens: Optional[np.ndarray] = None       # int32 [n]
 
     def triples(self) -> List[Tuple[Sequence[int], str, float]]:
         return [(self.quads[i].tolist(), self.texts[i], float(self.scores[i])) for i in range(len(self.texts))]
@@ -72,7 +74,8 @@ class OcrPipeline:
         for p in range(b):
             c = int(counts_h[p])
             texts = [cps[i, : len_h[i]].tobytes().decode("utf-32-le") for i in range(off, off + c)]
-            out.append(PageDetections(quads_h[off:off + c], texts, score_h[off:off + c], det_h[off:off + c], w, h))
+            out.append(PageDetections(quads_h[off:off + c], texts, score_h[off:off + c], det_h[off:off + c], w, h,
+                                      text_h[off:off + c], len_h[off:off + c]))
             off += c
         return out
 

@@ -29,7 +29,8 @@ def _worker(rank, world, port, n_pages, q):
     a, b = shard_range(n_pages, rank, world)
     ppr = -(-n_pages // world)
     out = all_gather_pages([_fake_page(i) for i in range(a, b)], cs, pages_per_rank=ppr)
-    q.put((rank, [(o["quads"].tolist(), o["texts"], o["scores"].tolist()) for o in out]))
+    assert int(out.counts.sum()) == sum(len(_fake_page(i).texts) for i in range(n_pages))
+    q.put((rank, [(o["quads"].tolist(), o["texts"], o["scores"].tolist()) for o in out.pages()]))
     dist.destroy_process_group()
 
 
