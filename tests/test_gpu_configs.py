@@ -1,0 +1,83 @@
+"""GPU parity at BASELINE.json's full configuration sizes (configs[1]..[3]) through size-independent properties
+(batch invariance, idempotence) plus a direct oracle comparison on a bounded sample of the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import close_stats
+from lumina_ocr import arch, synth
+from lumina_ocr.pipeline import OcrPipeline
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config2_det_batch32_1024(engine, det_weights):
+    """DBNet-R18 detection only, batch=32 1024x1024 synthetic pages."""
+    from oracle import nets
+    base = np.stack([synth.synth_page(1024, 1024, 1234 + i, n_lines=24)[0] for i in range(4)])
+    pages = torch.from_numpy(np.concatenate([base] * 8)).cuda()            # 32 pages, 4 distinct
+    engine.load_det(det_weights)
+    prob = engine.det_forward(pages)
+    torch.cuda.synchronize()
+    assert prob.shape == (32, 1024, 1024)
+    bits = prob.view(torch.int16)
+    for r in range(1, 8):                                                  # a page's result cannot depend on its batch slot
+        assert torch.equal(bits[:4], bits[4 * r:4 * r + 4])
+    ref = nets.det_forward(det_weights, base[:1], mode="bf16")            # one full-size page against the oracle
+    st = close_stats(prob[0].float().cpu().numpy(), ref[0])
+    assert st["within4"] > 0.98 and st["max_abs"] < 0.06, st
+    boxes, scores, counts = engine.det_postprocess(prob, 1024, 1024, **arch.TEXT_PATH_POST)
+    c = counts.cpu().numpy()
+    assert (c[:4] > 10).all() and all((c[:4] == c[4 * r:4 * r + 4]).all() for r in range(1, 8))
+    assert torch.equal(boxes[:4], boxes[4:8])
+
+
+def test_config3_rec_batch512(engine, rec_weights):
+    """CRNN-MobileNetV3 recognition + CTC greedy, batch=512 32x320 line crops."""
+    from oracle import nets
+    rng = np.random.default_rng(4321)
+    base = np.stack([synth.synth_crop(rng)[0] for _ in range(64)])
+    crops = torch.from_numpy(np.concatenate([base] * 8)).cuda()            # 512 crops, 64 distinct
+    engine.load_rec(rec_weights)
+    engine.set_option("rec_sub_batch", 200)                                # ragged sub-batches: 200 + 200 + 112
+    idx, prob = engine.rec_forward(crops)
+    text, length, score = engine.ctc_decode(idx, prob)
+    engine.set_option("rec_sub_batch", 2048)
+    idx2, prob2 = engine.rec_forward(crops)
+    torch.cuda.synchronize()
+    assert torch.equal(idx, idx2) and torch.equal(prob, prob2)            # sub-batching is invisible
+    for r in range(1, 8):
+        assert torch.equal(idx[:64], idx[64 * r:64 * r + 64])
+    ridx, rprob, _, _ = nets.rec_forward(rec_weights, base[:8])
+    agree = float((idx[:8].cpu().numpy() == ridx).mean())
+    assert agree > 0.8, agree
+    ref = nets.ctc_greedy(idx[:8].cpu().numpy(), prob[:8].cpu().numpy(), arch.ctc_charset())   # decode is exact on the same ids
+    cs = arch.ctc_charset()
+    for i in range(8):
+        got = "".join(cs[k] for k in text[i, : int(length[i])].cpu().tolist())
+        assert got == ref[i][0] and np.float32(score[i].item()) == np.float32(ref[i][1])
+
+
+def test_config4_end_to_end_a4_pages_and_detector_recall(engine, det_weights, rec_weights):
+    """End-to-end det+rec on A4@200DPI pages: batch invariance + the hand-set text path really finds the rendered lines."""
+    page, gt = synth.synth_page(2339, 1654, 2024)
+    pages = torch.from_numpy(np.stack([page] * 3)).cuda()
+    engine.load_det(det_weights)
+    engine.load_rec(rec_weights)
+    pipe = OcrPipeline(engine, post=arch.TEXT_PATH_POST)
+    dets, processed = pipe.run(pages)
+    assert processed.shape == (3, 2000, 1414, 3)                           # the reference's 2000-px cap with int() truncation
+    assert np.array_equal(dets[0].quads, dets[1].quads) and dets[0].texts == dets[2].texts
+    sc = 1414 / 1654
+    hit = 0
+    for g in gt:                                                           # ground-truth line boxes of the synthetic page
+        gx0, gy0, gx1, gy1 = [v * sc for v in g["box"]]
+        for q in dets[0].quads:
+            x0, y0, x1, y1 = q[0], q[1], q[4], q[5]
+            ix = max(0.0, min(gx1, x1) - max(gx0, x0)); iy = max(0.0, min(gy1, y1) - max(gy0, y0))
+            inter = ix * iy
+            union = (gx1 - gx0) * (gy1 - gy0) + (x1 - x0) * (y1 - y0) - inter
+            if union > 0 and inter / union > 0.5:
+                hit += 1
+                break
+    assert hit >= 0.75 * len(gt), (hit, len(gt), len(dets[0].quads))
