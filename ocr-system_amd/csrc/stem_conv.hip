@@ -31,21 +31,40 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
     const int tile_y = trem / tiles_x, tile_x = trem - tile_y * tiles_x;
     const int vw = p.valid_w_per_img ? p.valid_w_per_img[n_img] : p.valid_w;
     const int vh = p.valid_h;
-    const uint8_t* img = p.x + (size_t)n_img * p.H * p.W * 3;
 
-    // ---- stage + normalise the halo ----
+    // ---- stage + normalise the halo: aligned 4-byte loads of each halo row segment, bytes extracted in registers ----
     const int iy0 = tile_y * TH * 2 - 1, ix0 = tile_x * TW * 2 - 1;
-    for (int i = tid; i < HH * HW * 3; i += 256) {
-        const int hy = i / (HW * 3), rem = i - hy * HW * 3;
-        const int hx = rem / 3, c = rem - hx * 3;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        float v = 0.f;
-        if (iy >= 0 && iy < vh && ix >= 0 && ix < vw) {
-            const float u = (float)img[((size_t)iy * p.W + ix) * 3 + c];
-            v = u * p.scale[c];
-            v = v + p.shift[c];
+    {
+        constexpr int SEG = HW * 3;                       // 195 bytes of a halo row
+        constexpr int WPR = (SEG + 3) / 4 + 1;            // aligned words that can cover it (50)
+        const long long img_off = (long long)n_img * p.H * p.W * 3;   // addresses are aligned relative to p.x (allocation base), not to this image
+        const long long all_bytes = (long long)p.N * p.H * p.W * 3;
+        for (int i = tid; i < HH * WPR; i += 256) {
+            const int hy = i / WPR, wi = i - hy * WPR;
+            const int iy = iy0 + hy;
+            if (iy < 0 || iy >= vh) {                      // whole row outside the page: zeros (normalised space)
+                for (int b = 0; b < 4; ++b) { const int e = wi * 4 + b; if (e < SEG) halo[hy * ROW + e] = 0; }
+                continue;
+            }
+            const long long seg0 = img_off + ((long long)iy * p.W + ix0) * 3;   // byte offset of the segment start (may be < 0 at x = -1)
+            const long long a0 = (seg0 & ~3ll) + 4ll * wi;                // aligned word this thread fetches
+            uint32_t word = 0;
+            if (a0 >= 0 && a0 + 4 <= all_bytes) word = *reinterpret_cast<const uint32_t*>(p.x + a0);
+            else for (int b = 0; b < 4; ++b) if (a0 + b >= 0 && a0 + b < all_bytes) word |= (uint32_t)p.x[a0 + b] << (8 * b);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long long e = a0 + b - seg0;          // element index inside the row segment
+                if (e < 0 || e >= SEG) continue;
+                const int hx = (int)e / 3, c = (int)e - hx * 3;
+                const int ix = ix0 + hx;
+                float v = 0.f;
+                if (ix >= 0 && ix < vw) {
+                    v = (float)((word >> (8 * b)) & 0xffu) * p.scale[c];
+                    v = v + p.shift[c];
+                }
+                halo[hy * ROW + (int)e] = f32_to_bf16(v);
+            }
         }
-        halo[hy * ROW + rem] = f32_to_bf16(v);
     }
     __syncthreads();
 
