@@ -28,6 +28,10 @@ struct ConvParams {
     // [N, 4*Ho, 4*Wo] and the intermediate 64-channel tensor is never written.
     const bf16_t* fuse_w;
     float fuse_b;
+    // 1x1 only: squeeze-excite gate fused into the operand staging: x[n, p, c] is multiplied by gate[n, c] (bf16, one rounding)
+    // before the contraction; gate_hw = pixels per image (the flat GEMM view hides the image boundaries)
+    const bf16_t* gate;
+    int gate_hw;
     int dbg_skip;   // timing experiments only (LUMINA_CONV_DBG): 1 skip weight reloads, 2 skip halo reloads, 4 skip MFMAs (wrong results)
     int pix_limit;  // flat-GEMM mode (1x1): pixels >= pix_limit of an image are neither read nor written (0 = off)
 };

@@ -61,6 +61,16 @@ struct Cfg {
 
 __device__ __forceinline__ bf16x8_t lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 
+// 8 x (bf16 * bf16 -> fp32 -> bf16, round to nearest even): the fused squeeze-excite scaling
+__device__ __forceinline__ uint32_t mul_bf16x2(uint32_t a, uint32_t b) {
+    const float lo = __uint_as_float(a << 16) * __uint_as_float(b << 16);
+    const float hi = __uint_as_float(a & 0xFFFF0000u) * __uint_as_float(b & 0xFFFF0000u);
+    return pack_bf16x2(lo, hi);
+}
+__device__ __forceinline__ uint4 mul_bf16x8(uint4 a, uint4 b) {
+    return make_uint4(mul_bf16x2(a.x, b.x), mul_bf16x2(a.y, b.y), mul_bf16x2(a.z, b.z), mul_bf16x2(a.w, b.w));
+}
+
 template <int KS, int S, int BN, int CK, int TW, int NW, int DB, int MT>
 __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void conv_mfma_kernel(const ConvParams p) {
     using C = Cfg<KS, S, BN, CK, TW, NW, DB, MT>;
@@ -90,6 +100,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
 
     // ---- per-thread staging descriptors (independent of the chunk) ----
     int a_goff[C::AIT], a_loff[C::AIT];
+    int a_gate[KS == 1 ? C::AIT : 1];   // fused SE gate (1x1 layers): offset of this item's 8 gate values, -1 = none
     const int iy0 = tile_y * C::TH * S - C::PAD, ix0 = tile_x * TW * S - C::PAD;
 #pragma unroll
     for (int it = 0; it < C::AIT; ++it) {
@@ -101,9 +112,11 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         const bool inb = item && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && (p.pix_limit == 0 || iy * p.W + ix < p.pix_limit);
         a_goff[it] = inb ? (iy * p.W + ix) * p.Cin + c * 8 : -1;
         a_loff[it] = item ? (c * C::PLANE_A + hy * C::HWP + hx) * 16 : -1;
+        if constexpr (KS == 1) a_gate[it] = (inb && p.gate != nullptr) ? ((iy * p.W + ix) / p.gate_hw) * p.Cin + c * 8 : -1;
     }
 
     uint4 a_reg[C::AIT], w_reg[C::WIT];
+    uint4 g_reg[KS == 1 ? C::AIT : 1];
 #define ISSUE_LOADS(chunk_)                                                                          \
     {                                                                                                \
         const bf16_t* xa = ximg + (chunk_) * CK;                                                     \
@@ -112,6 +125,11 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
             uint4 t_ = make_uint4(0, 0, 0, 0);                                                       \
             if (a_goff[it] >= 0 && !skipa_) t_ = *reinterpret_cast<const uint4*>(xa + a_goff[it]);   \
             a_reg[it] = t_;                                                                          \
+            if constexpr (KS == 1) {                                                                 \
+                uint4 g_ = make_uint4(0, 0, 0, 0);                                                   \
+                if (a_gate[it] >= 0) g_ = *reinterpret_cast<const uint4*>(p.gate + a_gate[it] + (chunk_) * CK); \
+                g_reg[it] = g_;                                                                      \
+            }                                                                                        \
         }                                                                                            \
         const uint4* wsrc = reinterpret_cast<const uint4*>(wbase + (size_t)(chunk_) * C::W_ITEMS * 8); \
         _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
@@ -123,8 +141,10 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     }
 #define WRITE_LDS(boff_)                                                                             \
     {                                                                                                \
-        _Pragma("unroll") for (int it = 0; it < C::AIT; ++it)                                        \
+        _Pragma("unroll") for (int it = 0; it < C::AIT; ++it) {                                      \
+            if constexpr (KS == 1) { if (a_gate[it] >= 0) a_reg[it] = mul_bf16x8(a_reg[it], g_reg[it]); } \
             if (a_loff[it] >= 0) *reinterpret_cast<uint4*>(sA + (boff_) + a_loff[it]) = a_reg[it];   \
+        }                                                                                            \
         _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
             const int i = gtid + GTHR * it;                                                          \
             if (C::W_ITEMS % GTHR == 0 || i < C::W_ITEMS) *reinterpret_cast<uint4*>(sW + (boff_) + i * 16) = w_reg[it]; \

@@ -85,4 +85,4 @@ int eng_rec_forward(lumina_ocr* eng, const uint8_t* crops, const int* widths, in
 int eng_ws_reserve(lumina_ocr* eng, size_t bytes);
 void* eng_ws_alloc(lumina_ocr* eng, size_t bytes);
 int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4* y, const Tensor4* res, int res_shift, int out_mode,
-                 int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st);
+                 int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st, const bf16_t* gate = nullptr);

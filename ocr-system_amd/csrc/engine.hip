@@ -198,8 +198,9 @@ int eng_load_det(lumina_ocr* eng, const void* blob, size_t n) {
 
 // ------------------------------------------------------------------------------ conv dispatch
 int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4* y, const Tensor4* res, int res_shift, int out_mode,
-                 int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st) {
+                 int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st, const bf16_t* gate) {
     ConvParams p{};
+    p.gate = gate; p.gate_hw = x.h * x.w;
     p.x = x.p; p.wpk = L.wpk; p.bias = L.bias; p.res = res ? res->p : nullptr; p.y = y->p;
     p.Cin = L.cin; p.Cout = L.cout; p.act = L.act;
     p.out_mode = out_mode; p.up_shift = up_shift; p.convt_c = L.convt_c;
@@ -502,15 +503,14 @@ static int rec_forward_sub(lumina_ocr* eng, const uint8_t* crops, const int* wid
         const int ho = (x.h + 2 * (B.k / 2) - B.k) / B.stride_h + 1;
         Tensor4 d = ws_tensor(eng, N, ho, x.w, cp16(B.exp));
         LAUNCH("dwconv", dwconv_launch(e1.p, B.dw.w, B.dw.bias, d.p, N, e1.h, e1.w, e1.c, B.k, B.stride_h, B.act, st));
+        const bf16_t* se_gate_ptr = nullptr;
         if (B.se) {
             bf16_t* gate = static_cast<bf16_t*>(eng_ws_alloc(eng, (size_t)N * d.c * sizeof(bf16_t)));
-            Tensor4 s = ws_tensor(eng, N, d.h, d.w, d.c);
             LAUNCH("se_gate", se_gate_launch(d.p, B.sel.w1, B.sel.b1, B.sel.w2, B.sel.b2, gate, N, d.h * d.w, d.c, B.sel.mid, st));
-            LAUNCH("se_scale", se_scale_launch(d.p, gate, s.p, N, d.h * d.w, d.c, st));
-            d = s;
+            se_gate_ptr = gate;   // the scaling itself is fused into the project conv's operand staging
         }
         Tensor4 o = ws_tensor(eng, N, d.h, d.w, cp16(B.cout));
-        RUN(eng_run_conv(eng, B.project, d, &o, B.res ? &x : nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
+        RUN(eng_run_conv(eng, B.project, d, &o, B.res ? &x : nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st, se_gate_ptr));
         tap(eng, ("rec.b" + std::to_string(bi)).c_str(), o);
         x = o;
     }
