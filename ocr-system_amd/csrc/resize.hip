@@ -129,49 +129,60 @@ __device__ __forceinline__ uint8_t blend_u8(int deg, int v, float alpha) {
     return (uint8_t)t;
 }
 
+// contrast: 4 bytes per thread (the image size H*W*3 need not be a multiple of 4: the tail is done bytewise)
 __global__ void contrast_kernel(const uint8_t* img, uint8_t* out, const unsigned long long* sums, int HW, float alpha) {
     const int n = blockIdx.y;
     const int mean = (int)((double)sums[n] / (double)HW + 0.5);
-    const size_t total = (size_t)HW * 3;
+    const unsigned total = (unsigned)HW * 3u;
     const uint8_t* p = img + (size_t)n * total;
     uint8_t* o = out + (size_t)n * total;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) o[i] = blend_u8(mean, p[i], alpha);
+    const unsigned mis = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);          // leading bytes until 4-byte alignment
+    const unsigned head = mis ? 4u - mis : 0u;
+    const bool same = (reinterpret_cast<uintptr_t>(o) & 3u) == mis;                // in/out equally aligned (they are: same layout)
+    const unsigned words = same && total > head ? (total - head) / 4u : 0u;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(p + head + 4u * i);
+        const uint32_t r0 = blend_u8(mean, (int)(w & 0xff), alpha), r1 = blend_u8(mean, (int)((w >> 8) & 0xff), alpha);
+        const uint32_t r2 = blend_u8(mean, (int)((w >> 16) & 0xff), alpha), r3 = blend_u8(mean, (int)(w >> 24), alpha);
+        *reinterpret_cast<uint32_t*>(o + head + 4u * i) = r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
+    }
+    if (blockIdx.x == 0) {
+        for (unsigned i = threadIdx.x; i < head && i < total; i += blockDim.x) o[i] = blend_u8(mean, p[i], alpha);
+        for (unsigned i = head + 4u * words + threadIdx.x; i < total; i += blockDim.x) o[i] = blend_u8(mean, p[i], alpha);
+    }
 }
 
+// sharpen: grid (x-chunks, rows, images): no 64-bit index arithmetic, one output byte per thread, 9 neighbour bytes
 __global__ void sharpen_kernel(const uint8_t* img, uint8_t* out, int H, int W, float alpha) {
-    const int n = blockIdx.y;
-    const size_t total = (size_t)H * W * 3;
-    const uint8_t* p = img + (size_t)n * total;
-    uint8_t* o = out + (size_t)n * total;
-    const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % 3);
-        const size_t px = i / 3;
-        const int x = (int)(px % W), y = (int)(px / W);
-        const int v = p[i];
-        int deg = v;
-        if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
-            float ss = 0.5f;
-            // Pillow order: row y+1 (kernel[0..2]), row y (kernel[3..5]), row y-1 (kernel[6..8]); left-to-right adds
-            const uint8_t* r1 = p + ((size_t)(y + 1) * W + x) * 3 + c;
-            const uint8_t* r0 = p + ((size_t)y * W + x) * 3 + c;
-            const uint8_t* r_1 = p + ((size_t)(y - 1) * W + x) * 3 + c;
-            float a = __fmul_rn((float)r1[-3], k1);
-            a = __fadd_rn(a, __fmul_rn((float)r1[0], k1));
-            a = __fadd_rn(a, __fmul_rn((float)r1[3], k1));
-            ss = __fadd_rn(ss, a);
-            a = __fmul_rn((float)r0[-3], k1);
-            a = __fadd_rn(a, __fmul_rn((float)r0[0], k5));
-            a = __fadd_rn(a, __fmul_rn((float)r0[3], k1));
-            ss = __fadd_rn(ss, a);
-            a = __fmul_rn((float)r_1[-3], k1);
-            a = __fadd_rn(a, __fmul_rn((float)r_1[0], k1));
-            a = __fadd_rn(a, __fmul_rn((float)r_1[3], k1));
-            ss = __fadd_rn(ss, a);
-            deg = ss <= 0.f ? 0 : (ss >= 255.f ? 255 : (int)ss);
-        }
-        o[i] = blend_u8(deg, v, alpha);
+    const int n = blockIdx.z, y = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;   // byte inside the row: x*3 + c
+    const int rowb = W * 3;
+    if (e >= rowb) return;
+    const size_t base = ((size_t)n * H + y) * rowb;
+    const uint8_t* r0 = img + base + e;
+    const int v = r0[0];
+    int deg = v;
+    if (e >= 3 && e < rowb - 3 && y > 0 && y < H - 1) {
+        const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
+        const uint8_t* r1 = r0 + rowb;
+        const uint8_t* r_1 = r0 - rowb;
+        float ss = 0.5f;
+        // Pillow order: row y+1 (kernel[0..2]), row y (kernel[3..5]), row y-1 (kernel[6..8]); left-to-right adds
+        float a = __fmul_rn((float)r1[-3], k1);
+        a = __fadd_rn(a, __fmul_rn((float)r1[0], k1));
+        a = __fadd_rn(a, __fmul_rn((float)r1[3], k1));
+        ss = __fadd_rn(ss, a);
+        a = __fmul_rn((float)r0[-3], k1);
+        a = __fadd_rn(a, __fmul_rn((float)r0[0], k5));
+        a = __fadd_rn(a, __fmul_rn((float)r0[3], k1));
+        ss = __fadd_rn(ss, a);
+        a = __fmul_rn((float)r_1[-3], k1);
+        a = __fadd_rn(a, __fmul_rn((float)r_1[0], k1));
+        a = __fadd_rn(a, __fmul_rn((float)r_1[3], k1));
+        ss = __fadd_rn(ss, a);
+        deg = ss <= 0.f ? 0 : (ss >= 255.f ? 255 : (int)ss);
     }
+    out[base + e] = blend_u8(deg, v, alpha);
 }
 
 inline int grid_for(size_t total) {
@@ -257,6 +268,6 @@ hipError_t enhance_launch(const uint8_t* img, uint8_t* tmp, uint8_t* out, unsign
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(gray_sum_kernel, dim3(gx > 64 ? 64 : gx, N), dim3(256), 0, st, img, sums_dev, HW);
     hipLaunchKernelGGL(contrast_kernel, dim3(gx, N), dim3(256), 0, st, img, tmp, sums_dev, HW, contrast);
-    hipLaunchKernelGGL(sharpen_kernel, dim3(gx, N), dim3(256), 0, st, tmp, out, H, W, sharpness);
+    hipLaunchKernelGGL(sharpen_kernel, dim3((W * 3 + 255) / 256, H, N), dim3(256), 0, st, tmp, out, H, W, sharpness);
     return hipGetLastError();
 }
