@@ -136,7 +136,7 @@ int lumina_ocr_conv2d(lumina_ocr_t* h, const uint16_t* x_dev, int n, int height,
     L.name = "conv2d"; L.ks = ks; L.stride = stride; L.cin = cin; L.cout = cout; L.act = act;
     if (!conv_pick_cfg(ks, stride, cin, cout, &L.cfg)) return locr_fail(h, "conv2d", "unsupported ks/stride/cin");
     std::vector<bf16_t> packed(conv_packed_weight_elems(cout, ks, cin, L.cfg.bn));
-    pack_conv_weights(w_host, cout, ks, cin, L.cfg.bn, L.cfg.ck, packed.data());
+    pack_conv_weights(w_host, cout, ks, cin, L.cfg.bn, L.cfg.ck, packed.data(), L.cfg.nw == 6 ? 1 : 0);
     const int ntiles = (cout + L.cfg.bn - 1) / L.cfg.bn;
     std::vector<float> bias((size_t)ntiles * L.cfg.bn, 0.f);
     memcpy(bias.data(), bias_host, sizeof(float) * cout);

@@ -34,6 +34,7 @@ struct ConvParams {
     int gate_hw;
     int dbg_skip;   // timing experiments only (LUMINA_CONV_DBG): 1 skip weight reloads, 2 skip halo reloads, 4 skip MFMAs (wrong results)
     int pix_limit;  // flat-GEMM mode (1x1): pixels >= pix_limit of an image are neither read nor written (0 = off)
+    const bf16_t* zeros;  // >= 16 bytes of zeros in device memory (LDS-DMA variant: source of the out-of-image halo)
 };
 
 struct ConvKernelCfg {
@@ -43,7 +44,8 @@ struct ConvKernelCfg {
 // Size in bytes of the packed weight image for (cout, ks, cin) under cfg.
 size_t conv_packed_weight_elems(int cout_gemm, int ks, int cin, int bn);
 // Pack OHWI bf16 weights [cout_gemm][ks][ks][cin] into [ntile][chunk][plane][tap*BN + n][8].
-void pack_conv_weights(const bf16_t* ohwi, int cout_gemm, int ks, int cin, int bn, int ck, bf16_t* out);
+// row_major != 0 (cfg.nw == 6, the LDS-DMA kernel): [ntile][chunk][tap*BN + n][ck].
+void pack_conv_weights(const bf16_t* ohwi, int cout_gemm, int ks, int cin, int bn, int ck, bf16_t* out, int row_major = 0);
 
 // Choose a kernel configuration for a layer; launch it. Returns hipSuccess or an error.
 bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cfg);

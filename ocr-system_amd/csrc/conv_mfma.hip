@@ -31,6 +31,7 @@ template <int KS, int S, int BN, int CK, int TW, int NW = 4, int DB = 0, int MT 
 struct Cfg {
     static constexpr int NTHR = NW * 64;
     static constexpr bool PP = (DB == 2);           // ping-pong: two 4-wave groups alternate compute / stage roles
+    static constexpr bool DMA = (DB == 3);          // operands arrive by LDS-DMA (global_load_lds) into a 2-deep LDS ring
     static constexpr int GTHR = PP ? 256 : NTHR;    // threads that cooperate on one LDS buffer
     static constexpr int TH = (GTHR / 64) * MT;     // TW == 32: every wave owns MT pixel rows (MT 32-pixel MFMA column tiles)
     static constexpr int PAD = (KS == 3) ? 1 : 0;
@@ -45,13 +46,19 @@ struct Cfg {
     static constexpr int WROWS = TAPS * BN;
     static constexpr int PLANE_W = WROWS;
     static constexpr int NT = BN / 32;
-    static constexpr int A_BYTES = PLANE_A * NPL * 16;
+    static constexpr int A_BYTES = DMA ? HPX * NPL * 16 : PLANE_A * NPL * 16;
     static constexpr int W_BYTES = PLANE_W * NPL * 16;
+    // LDS addressing of one 16-byte entry (pixel or weight row, 8-channel slice): the plane layout keeps a slice's entries
+    // together (register staging scatters into it); the DMA layout is the lane-linear image a wave's global_load_lds writes,
+    // [pixel][slice] — with CK == 16 (two slices) a fragment read is still one contiguous, conflict-free 1 KB
+    static constexpr int A_PIX = DMA ? NPL * 16 : 16, A_SL = DMA ? 16 : PLANE_A * 16;
+    static constexpr int W_ROW = DMA ? NPL * 16 : 16, W_SL = DMA ? 16 : PLANE_W * 16;
     static constexpr int STAGE_PITCH = BN * 2 + 16;
     static constexpr int STAGE_BYTES = TH * TW * STAGE_PITCH;
     static constexpr int BUF_BYTES = A_BYTES + W_BYTES;
     static constexpr int XCHG_BYTES = PP ? 256 * MT * NT * 16 * 4 : 0;  // fp32 accumulators of the second group
     static constexpr int LDS_BYTES = (BUF_BYTES * (DB ? 2 : 1)) > (XCHG_BYTES + STAGE_BYTES) ? (BUF_BYTES * (DB ? 2 : 1)) : (XCHG_BYTES + STAGE_BYTES);
+    static_assert(!DMA || (CK == 16 && KS == 3 && S == 1), "DMA variant: 3x3 / stride 1 / 16-channel chunks");
     static constexpr int A_ITEMS = HH * HW * NPL;
     static constexpr int AIT = (A_ITEMS + GTHR - 1) / GTHR;
     static constexpr int W_ITEMS = WROWS * NPL;
@@ -72,7 +79,7 @@ __device__ __forceinline__ uint4 mul_bf16x8(uint4 a, uint4 b) {
 }
 
 template <int KS, int S, int BN, int CK, int TW, int NW, int DB, int MT>
-__global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void conv_mfma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(NW * 64, ((DB == 1 || DB == 2) ? NW / 4 : (BN <= 64 ? 2 : 1))) void conv_mfma_kernel(const ConvParams p) {
     using C = Cfg<KS, S, BN, CK, TW, NW, DB, MT>;
     constexpr int NTHR = C::NTHR, GTHR = C::GTHR;
     constexpr bool PP = C::PP;
@@ -99,6 +106,11 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     const bf16_t* wbase = p.wpk + (size_t)ntile * nchunks * C::W_ITEMS * 8;
 
     // ---- per-thread staging descriptors (independent of the chunk) ----
+    // timing experiment (LUMINA_CONV_DBG & 8, CK == 16 only): address the input as if it were stored channel-blocked
+    // [C/16][H][W][16] — same bytes per image, wrong values — to price the NHWC line over-fetch of 16-channel chunks
+    const bool blk_dbg = CK == 16 && (p.dbg_skip & 8);
+    const int pstride = blk_dbg ? 16 : p.Cin;
+    const int cadv = blk_dbg ? p.H * p.W * 16 : CK;
     int a_goff[C::AIT], a_loff[C::AIT];
     int a_gate[KS == 1 ? C::AIT : 1];   // fused SE gate (1x1 layers): offset of this item's 8 gate values, -1 = none
     const int iy0 = tile_y * C::TH * S - C::PAD, ix0 = tile_x * TW * S - C::PAD;
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         const int iy = iy0 + hy, ix = ix0 + hx;
         const bool item = i < C::A_ITEMS;
         const bool inb = item && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && (p.pix_limit == 0 || iy * p.W + ix < p.pix_limit);
-        a_goff[it] = inb ? (iy * p.W + ix) * p.Cin + c * 8 : -1;
+        a_goff[it] = inb ? (iy * p.W + ix) * pstride + c * 8 : -1;
         a_loff[it] = item ? (c * C::PLANE_A + hy * C::HWP + hx) * 16 : -1;
         if constexpr (KS == 1) a_gate[it] = (inb && p.gate != nullptr) ? ((iy * p.W + ix) / p.gate_hw) * p.Cin + c * 8 : -1;
     }
@@ -119,7 +131,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     uint4 g_reg[KS == 1 ? C::AIT : 1];
 #define ISSUE_LOADS(chunk_)                                                                          \
     {                                                                                                \
-        const bf16_t* xa = ximg + (chunk_) * CK;                                                     \
+        const bf16_t* xa = ximg + (chunk_) * cadv;                                                   \
         const bool skipa_ = (p.dbg_skip & 2) && (chunk_) > 0, skipw_ = (p.dbg_skip & 1) && (chunk_) > 0; \
         _Pragma("unroll") for (int it = 0; it < C::AIT; ++it) {                                      \
             uint4 t_ = make_uint4(0, 0, 0, 0);                                                       \
@@ -151,6 +163,29 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         }                                                                                            \
     }
 
+    // LDS-DMA staging: every wave-instruction moves 64 x 16 B straight into the lane-linear LDS image (no VGPR round trip,
+    // no ds_write pass); halo pixels outside the image read a 16-byte block of zeros instead.
+#define DMA_ISSUE(chunk_, boff_)                                                                     \
+    {                                                                                                \
+        const bf16_t* xa = ximg + (chunk_) * cadv;                                                   \
+        const bool skipa_ = (p.dbg_skip & 2) && (chunk_) > 0, skipw_ = (p.dbg_skip & 1) && (chunk_) > 0; \
+        _Pragma("unroll") for (int it = 0; it < C::AIT; ++it) {                                      \
+            const int i = tid + NTHR * it;                                                           \
+            if ((C::A_ITEMS % NTHR == 0 || i < C::A_ITEMS) && !skipa_) {                             \
+                const bf16_t* src_ = a_goff[it] >= 0 ? xa + a_goff[it] : p.zeros;                    \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_), \
+                    (__attribute__((address_space(3))) void*)(sA + (boff_) + (i - lane) * 16), 16, 0, 0); \
+            }                                                                                        \
+        }                                                                                            \
+        const bf16_t* wsrc = wbase + (size_t)(chunk_) * C::W_ITEMS * 8;                              \
+        _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
+            const int i = tid + NTHR * it;                                                           \
+            if ((C::W_ITEMS % NTHR == 0 || i < C::W_ITEMS) && !skipw_)                               \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 8), \
+                    (__attribute__((address_space(3))) void*)(sW + (boff_) + (i - lane) * 16), 16, 0, 0); \
+        }                                                                                            \
+    }
+
     f32x16_t acc[MT][C::NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -164,9 +199,9 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int ty = wave * MT + mt, tx = r;  // TW == 32
-        aoff[mt] = (h * C::PLANE_A + (ty * S) * C::HWP + tx * S) * 16;
+        aoff[mt] = h * C::A_SL + ((ty * S) * C::HWP + tx * S) * C::A_PIX;
     }
-    const int woff = (h * C::PLANE_W + r) * 16;
+    const int woff = h * C::W_SL + r * C::W_ROW;
 
     // Fragment reads are software-pipelined one (tap, k-step) ahead of the MFMAs that consume them: the reads of step s+1 are
     // in flight while the 2*NT MFMAs of step s issue (hipcc otherwise places every ds_read right in front of its MFMA and the
@@ -177,9 +212,9 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     {                                                                                                              \
         const int tap_ = (st_) / (CK / 16), kc_ = (st_) % (CK / 16), kh_ = tap_ / KS, kw_ = tap_ % KS;              \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
-            bfr[set_][mt] = lds_frag(sA + (boff_) + aoff[mt] + ((2 * kc_) * C::PLANE_A + kh_ * C::HWP + kw_) * 16); \
+            bfr[set_][mt] = lds_frag(sA + (boff_) + aoff[mt] + (2 * kc_) * C::A_SL + (kh_ * C::HWP + kw_) * C::A_PIX); \
         _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                                                       \
-            afr[set_][nt] = lds_frag(sW + (boff_) + woff + ((2 * kc_) * C::PLANE_W + tap_ * BN + nt * 32) * 16);    \
+            afr[set_][nt] = lds_frag(sW + (boff_) + woff + (2 * kc_) * C::W_SL + (tap_ * BN + nt * 32) * C::W_ROW);   \
     }
 #define COMPUTE_CHUNK(boff_)                                                                                       \
     LOAD_FRAGS(boff_, 0, 0)                                                                                        \
@@ -195,7 +230,18 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
         }                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
     }
-    if constexpr (PP) {
+    if constexpr (C::DMA) {
+        // 2-deep LDS ring, ONE barrier per chunk: the DMA of chunk c+1 is issued right after the barrier that retires the reads
+        // of chunk c-1 (its target buffer) and flies under all MFMAs of chunk c; vmcnt(0) + barrier publish it.
+        DMA_ISSUE(0, 0);
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int boff = (chunk & 1) * C::BUF_BYTES;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (chunk + 1 < nchunks) DMA_ISSUE(chunk + 1, C::BUF_BYTES - boff);
+            COMPUTE_CHUNK(boff)
+        }
+    } else if constexpr (PP) {
         // Ping-pong: group g owns the chunks c == g (mod 2) and its own LDS buffer.  In half-period k the group k&1 issues the
         // loads of its next chunk and runs the MFMAs of chunk k, while the other group writes its already-arrived chunk k+1 to
         // LDS and then parks at the barrier: on every SIMD exactly one of its two waves is in an MFMA phase at any time, so
@@ -237,6 +283,7 @@ __global__ __launch_bounds__(NW * 64, (DB ? NW / 4 : (BN <= 64 ? 2 : 1))) void c
     }
 #undef COMPUTE_CHUNK
 #undef LOAD_FRAGS
+#undef DMA_ISSUE
 
     // ---------------- epilogue: bias + residual + act -> bf16 -> LDS stage -> coalesced store ----------------
     // All bias / residual loads are issued back to back BEFORE the barrier (one latency, not one per quad), the
@@ -420,9 +467,21 @@ size_t conv_packed_weight_elems(int cout_gemm, int ks, int cin, int bn) {
     return (size_t)ntiles * bn * ks * ks * cin;
 }
 
-void pack_conv_weights(const bf16_t* ohwi, int cout_gemm, int ks, int cin, int bn, int ck, bf16_t* out) {
+void pack_conv_weights(const bf16_t* ohwi, int cout_gemm, int ks, int cin, int bn, int ck, bf16_t* out, int row_major) {
     const int ntiles = (cout_gemm + bn - 1) / bn, taps = ks * ks, npl = ck / 8, nchunks = cin / ck;
     const size_t wrows = (size_t)taps * bn;
+    if (row_major) {  // LDS-DMA variant: [ntile][chunk][tap*BN + n][ck] — a chunk's slab is copied to LDS verbatim
+        for (int nt = 0; nt < ntiles; ++nt)
+            for (int chunk = 0; chunk < nchunks; ++chunk)
+                for (int tap = 0; tap < taps; ++tap)
+                    for (int n = 0; n < bn; ++n) {
+                        const int co = nt * bn + n;
+                        bf16_t* dst = out + (((size_t)nt * nchunks + chunk) * wrows + (size_t)tap * bn + n) * ck;
+                        for (int j = 0; j < ck; ++j)
+                            dst[j] = co < cout_gemm ? ohwi[((size_t)co * taps + tap) * cin + chunk * ck + j] : (bf16_t)0;
+                    }
+        return;
+    }
     for (int nt = 0; nt < ntiles; ++nt)
         for (int chunk = 0; chunk < nchunks; ++chunk)
             for (int c = 0; c < npl; ++c)
@@ -450,14 +509,14 @@ bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cf
     if (const char* e = getenv("LUMINA_CONV_CK3")) { if (ks == 3 && stride == 1 && cfg->bn == 64 && cin >= atoi(e)) cfg->ck = 16; }
     if (const char* e = getenv("LUMINA_CONV_NW")) {
         if (atoi(e) >= 8 && ks == 3 && stride == 1 && cfg->bn == 64 && cfg->ck == 32 && cin >= 64) cfg->nw = atoi(e);
-        if (atoi(e) == 5 && ks == 3 && stride == 1 && cfg->bn == 64 && cin >= 64) { cfg->nw = 5; cfg->ck = 16; }
+        if ((atoi(e) == 5 || atoi(e) == 6) && ks == 3 && stride == 1 && cfg->bn == 64 && cin >= 64) { cfg->nw = atoi(e); cfg->ck = 16; }
     }
     return true;
 }
 
 const char* conv_kernel_name(const ConvKernelCfg& c) {
     static thread_local char buf[64];
-    const int nw = c.nw >= 8 ? 8 : 4, db = c.nw == 8 ? 1 : (c.nw == 9 ? 2 : 0), mt = c.nw == 5 ? 4 : 2;
+    const int nw = c.nw >= 8 ? 8 : 4, db = c.nw == 8 ? 1 : (c.nw == 9 ? 2 : (c.nw == 6 ? 3 : 0)), mt = (c.nw == 5 || c.nw == 6) ? 4 : 2;
     snprintf(buf, sizeof(buf), "conv_mfma_kernel<%d,%d,%d,%d,32,%d,%d,%d>", c.ks, c.stride, c.bn, c.ck, nw, db, mt);  // as rocprofv3 prints it (modulo spaces)
     return buf;
 }
@@ -478,6 +537,12 @@ hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t strea
     if (cfg.nw == 5) {  // 4 waves, 4 pixel rows per wave: 16x32-pixel tile, 4x2 MFMA register tile, CK = 16
         p.tiles_y = ceil_div(p.Ho, 16);
         if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16) return launch_t<3, 1, 64, 16, 32, 4, 0, 4>(p, stream);
+        return hipErrorInvalidValue;
+    }
+    if (cfg.nw == 6) {  // same tile as nw == 5, operands by LDS-DMA into a 2-deep ring (row-major weight packing)
+        p.tiles_y = ceil_div(p.Ho, 16);
+        if (p.zeros == nullptr) return hipErrorInvalidValue;
+        if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16) return launch_t<3, 1, 64, 16, 32, 4, 3, 4>(p, stream);
         return hipErrorInvalidValue;
     }
     if (cfg.nw == 9) {  // ping-pong variant: 8 waves in two role-alternating groups on one 8x32 tile

@@ -112,10 +112,13 @@ static bool make_conv(lumina_ocr* eng, const std::map<std::string, HostBlobTenso
     std::vector<bf16_t> packed(conv_packed_weight_elems(cout_p, ks, cin_p, L->cfg.bn));
     pack_conv_weights(padded.data(), cout_p, ks, cin_p, L->cfg.bn, L->cfg.ck, packed.data());
     L->wpk = static_cast<bf16_t*>(dev_upload(eng, packed.data(), packed.size() * sizeof(bf16_t)));
+    // 16x32-tile kernel: operands by LDS-DMA into a 2-deep ring (nw == 6, default: +3..5 % on the 128..256-channel layers) or
+    // through registers (nw == 5, LUMINA_CONV_DMA=0)
+    static const int dma = getenv("LUMINA_CONV_DMA") != nullptr ? atoi(getenv("LUMINA_CONV_DMA")) : 1;
     if (ks == 3 && stride == 1 && L->cfg.bn == 64 && cin_p >= 64 && L->cfg.nw == 4) {
-        L->cfg_big = L->cfg; L->cfg_big.nw = 5; L->cfg_big.ck = 16;
+        L->cfg_big = L->cfg; L->cfg_big.nw = dma ? 6 : 5; L->cfg_big.ck = 16;
         std::vector<bf16_t> packed2(conv_packed_weight_elems(cout_p, ks, cin_p, 64));
-        pack_conv_weights(padded.data(), cout_p, ks, cin_p, 64, 16, packed2.data());
+        pack_conv_weights(padded.data(), cout_p, ks, cin_p, 64, 16, packed2.data(), dma ? 1 : 0);
         L->wpk_big = static_cast<bf16_t*>(dev_upload(eng, packed2.data(), packed2.size() * sizeof(bf16_t)));
     }
     const int ntiles = (cout_p + L->cfg.bn - 1) / L->cfg.bn;
@@ -200,6 +203,12 @@ int eng_load_det(lumina_ocr* eng, const void* blob, size_t n) {
 int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4* y, const Tensor4* res, int res_shift, int out_mode,
                  int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st, const bf16_t* gate) {
     ConvParams p{};
+    if (eng->zero_block == nullptr) {
+        const uint32_t z[64] = {0};
+        eng->zero_block = static_cast<bf16_t*>(dev_upload(eng, z, sizeof(z)));
+        if (!eng->zero_block) return locr_fail(eng, "conv", "zero block upload failed");
+    }
+    p.zeros = eng->zero_block;
     p.gate = gate; p.gate_hw = x.h * x.w;
     p.x = x.p; p.wpk = L.wpk; p.bias = L.bias; p.res = res ? res->p : nullptr; p.y = y->p;
     p.Cin = L.cin; p.Cout = L.cout; p.act = L.act;
@@ -233,8 +242,9 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     static const bool no_big = getenv("LUMINA_CONV_NO_BIG") != nullptr;
     const bool use1x1 = want1x1 && conv1x1_supported(L.cfg, p);
     // 16x32 tiles (less LDS and L2 traffic per MFMA) once they still give >= 2 workgroups per CU on all 256 CUs twice over
-    const long long big_blocks = (long long)p.N * ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32) * ((L.cout + 63) / 64);
-    const bool use_big = !no_big && !flat && L.wpk_big != nullptr && big_blocks >= 1024;
+    const long long big_blocks = (long long)p.N * ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32) * ((L.cout + L.cfg.bn - 1) / L.cfg.bn);
+    static const long long big_min = getenv("LUMINA_CONV_BIG_MIN") ? atoll(getenv("LUMINA_CONV_BIG_MIN")) : 1024;
+    const bool use_big = !no_big && !flat && L.wpk_big != nullptr && big_blocks >= big_min;
     ConvKernelCfg cfg = L.cfg;
     if (use_big) { cfg = L.cfg_big; p.wpk = L.wpk_big; }
     hipError_t e = use1x1 ? conv1x1_launch(p, flat ? (long long)p.pix_limit : (long long)p.N * p.H * p.W, st) : conv_launch(cfg, p, st);
