@@ -193,6 +193,7 @@ static int get_coeffs(lumina_ocr* h, int in_size, int out_size, lumina_ocr::Coef
         std::vector<int> bounds, kk;
         lumina_ocr::Coeffs c;
         lanczos_coeffs(in_size, out_size, &c.ksize, &bounds, &kk);
+        c.bounds_host = std::make_shared<std::vector<int>>(bounds);
         if (hipMalloc(reinterpret_cast<void**>(&c.bounds), bounds.size() * 4) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&c.kk), kk.size() * 4) != hipSuccess)
             return locr_fail(h, "resize", "hipMalloc coefficient tables");
@@ -234,14 +235,14 @@ int lumina_ocr_resize_lanczos(lumina_ocr_t* h, const uint8_t* in_dev, int n, int
             }
             dst = h->aux;
         }
-        hipError_t e = resample_launch(src, dst, c.bounds, c.kk, c.ksize, n, height, width, channels, out_w, 0, st);
+        hipError_t e = resample_launch(src, dst, c.bounds, c.kk, c.ksize, n, height, width, channels, out_w, 0, c.bounds_host->data(), st);
         if (e != hipSuccess) return locr_fail(h, "resize_lanczos", hipGetErrorString(e));
         src = dst; cur_w = out_w;
     }
     if (need_v) {
         lumina_ocr::Coeffs c;
         if (get_coeffs(h, height, out_h, &c)) return 1;
-        hipError_t e = resample_launch(src, out_dev, c.bounds, c.kk, c.ksize, n, height, cur_w, channels, out_h, 1, st);
+        hipError_t e = resample_launch(src, out_dev, c.bounds, c.kk, c.ksize, n, height, cur_w, channels, out_h, 1, c.bounds_host->data(), st);
         if (e != hipSuccess) return locr_fail(h, "resize_lanczos", hipGetErrorString(e));
     }
     return 0;

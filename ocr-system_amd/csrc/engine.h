@@ -1,6 +1,7 @@
 // Host-side engine: weight loading/packing, workspace, and the det / rec layer schedules.
 #pragma once
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -70,7 +71,7 @@ struct lumina_ocr {
     std::vector<double> conv_flops, conv_bytes;
     std::vector<std::string> conv_names, conv_kernels;
     // ---- pre-processing (resize / enhance) ----
-    struct Coeffs { int ksize = 0; int* bounds = nullptr; int* kk = nullptr; };
+    struct Coeffs { int ksize = 0; int* bounds = nullptr; int* kk = nullptr; std::shared_ptr<std::vector<int>> bounds_host; };
     std::map<std::pair<int, int>, Coeffs> coeff_cache;  // (in, out) -> device tables
     uint8_t* aux = nullptr; size_t aux_cap = 0;         // resize intermediate
     unsigned long long* sums = nullptr; int sums_cap = 0;

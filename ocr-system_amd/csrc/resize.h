@@ -6,8 +6,9 @@
 // Pillow-exact LANCZOS coefficient tables for one axis (host).
 void lanczos_coeffs(int in_size, int out_size, int* ksize_out, std::vector<int>* bounds, std::vector<int>* kk);
 // One resampling pass over [N,H,W,C] u8: axis 0 -> [N,H,out_len,C], axis 1 -> [N,out_len,W,C].
+// bounds_host: host copy of the bounds table (vertical pass: picks the tiled kernel when the row spans fit its LDS tile) or null.
 hipError_t resample_launch(const uint8_t* in, uint8_t* out, const int* bounds_dev, const int* kk_dev, int ksize, int N, int H, int W, int C,
-                           int out_len, int axis, hipStream_t st);
+                           int out_len, int axis, const int* bounds_host, hipStream_t st);
 // contrast (mean-gray blend) then sharpness (3x3 smooth blend) on RGB u8 [N,H,W,3]; tmp = scratch of the same size.
 hipError_t enhance_launch(const uint8_t* img, uint8_t* tmp, uint8_t* out, unsigned long long* sums_dev, int N, int H, int W, float contrast,
                           float sharpness, hipStream_t st);

@@ -103,6 +103,166 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t* in, uint
     }
 }
 
+// ---- LDS row tiles with arbitrary byte alignment -------------------------------------------------------------------------
+// Rows of W*C bytes are not 4-byte aligned in general.  fill_rows() copies `nrows` row segments (row r starts at flat byte
+// index g0 + r*row_stride) into LDS with ALIGNED 4-byte global loads: LDS row r (pitch words) holds the aligned words that
+// cover the segment, so the segment's byte 0 sits at LDS byte offset m_r = (address of the segment start) & 3 of its row.
+// All loads of a batch of 8 items per thread are issued before the first LDS write (one memory latency per batch, not one
+// per row).  f() transforms a loaded word (identity, or the contrast blend).
+template <typename F>
+__device__ __forceinline__ void fill_rows(uint32_t* lds, int pitch, int nw, const uint8_t* img, long long g0, long long row_stride, int nrows,
+                                          int rlo, int rhi, long long total, F f) {
+    const uintptr_t ibase = reinterpret_cast<uintptr_t>(img);
+    const int items = nrows * nw;
+    for (int i0 = 0; i0 < items; i0 += 256 * 8) {
+        uint32_t w[8];
+        int dst[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256 + (int)threadIdx.x;
+            dst[u] = -1;
+            w[u] = 0;
+            if (i < items) {
+                const int r = i / nw, k = i - r * nw;
+                if (r >= rlo && r < rhi) {
+                    const long long g = g0 + (long long)r * row_stride;
+                    const int m = (int)((ibase + (unsigned long long)g) & 3);
+                    const long long a = g - m + 4ll * k;
+                    dst[u] = r * pitch + k;
+                    if (a >= 0 && a + 4 <= total) w[u] = *reinterpret_cast<const uint32_t*>(img + a);
+                    else
+                        for (int b = 0; b < 4; ++b)
+                            if (a + b >= 0 && a + b < total) w[u] |= (uint32_t)img[a + b] << (8 * b);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (dst[u] >= 0) lds[dst[u]] = f(w[u]);
+    }
+}
+struct WordIdentity { __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return w; } };
+
+// Horizontal pass, RGB fast path (<= HK <= HKMAX taps, segment <= HPXMAX input pixels): one workgroup = HR rows x HX output pixels, one
+// output pixel (of all HR rows) per thread.  The thread's tap coefficients are fetched up front into registers, the HR input
+// row segments go to LDS by fill_rows(), results are staged in LDS and leave as aligned 4-byte stores.
+constexpr int HR = 8, HX = 256, HKMAX = 12, HPXMAX = 400;
+constexpr int HP_IN = (HPXMAX * 3 + 3) / 4 + 2 + HKMAX;   // LDS pitch (words) of an input row segment (+ slack for zero taps)
+constexpr int HP_OUT = (HX * 3 + 3) / 4 + 2;           // LDS pitch (words) of an output row segment
+template <int HK>
+__global__ __launch_bounds__(256) void resample_h_rgb_kernel(const uint8_t* in, uint8_t* out, const int* bounds, const int* kk, int ksize, int rows,
+                                                             int W, int Wo, long long total_in) {
+    __shared__ uint32_t lin[HR * HP_IN];
+    __shared__ uint32_t lout[HR * HP_OUT];
+    const int tid = threadIdx.x;
+    const int xo0 = blockIdx.x * HX, row0 = blockIdx.y * HR;
+    const int nx = min(HX, Wo - xo0), nrows = min(HR, rows - row0);
+    const int xo = xo0 + min(tid, nx - 1);
+    const int lo = bounds[2 * xo];
+    int kreg[HK];
+#pragma unroll
+    for (int j = 0; j < HK; ++j) kreg[j] = j < ksize ? kk[(size_t)xo * ksize + j] : 0;  // entries >= cnt are zero in the table
+    const int in_lo = bounds[2 * xo0];
+    const int in_hi = bounds[2 * (xo0 + nx - 1)] + bounds[2 * (xo0 + nx - 1) + 1];
+    const int rowb = W * 3;
+    const long long g0 = (long long)row0 * rowb + (long long)in_lo * 3;
+    const int nw = ((in_hi - in_lo) * 3 + 3 + 3) / 4;
+    fill_rows(lin, HP_IN, nw, in, g0, rowb, nrows, 0, nrows, total_in, WordIdentity());
+    __syncthreads();
+    const uintptr_t ibase = reinterpret_cast<uintptr_t>(in), obase = reinterpret_cast<uintptr_t>(out);
+    const uint8_t* lb = reinterpret_cast<const uint8_t*>(lin);
+    uint8_t* ob = reinterpret_cast<uint8_t*>(lout);
+    if (tid < nx) {
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+            if (r >= nrows) break;
+            const int m = (int)((ibase + (unsigned long long)(g0 + (long long)r * rowb)) & 3);
+            const uint8_t* p = lb + r * HP_IN * 4 + m + (lo - in_lo) * 3;
+            int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+#pragma unroll
+            for (int j = 0; j < HK; ++j) {  // straight-line: taps beyond the pixel's count have coefficient 0 (reads stay inside the LDS slack)
+                s0 += (int)p[3 * j] * kreg[j]; s1 += (int)p[3 * j + 1] * kreg[j]; s2 += (int)p[3 * j + 2] * kreg[j];
+            }
+            s0 >>= PRECISION_BITS; s1 >>= PRECISION_BITS; s2 >>= PRECISION_BITS;
+            const long long go = ((long long)(row0 + r) * Wo + xo0) * 3;
+            const int mo = (int)((obase + (unsigned long long)go) & 3);
+            uint8_t* o = ob + r * HP_OUT * 4 + mo + tid * 3;
+            o[0] = (uint8_t)(s0 < 0 ? 0 : (s0 > 255 ? 255 : s0));
+            o[1] = (uint8_t)(s1 < 0 ? 0 : (s1 > 255 ? 255 : s1));
+            o[2] = (uint8_t)(s2 < 0 ? 0 : (s2 > 255 ? 255 : s2));
+        }
+    }
+    __syncthreads();
+    const int segb = nx * 3;
+    for (int i = tid; i < nrows * HP_OUT; i += 256) {
+        const int r = i / HP_OUT, k = i - r * HP_OUT;
+        const long long go = ((long long)(row0 + r) * Wo + xo0) * 3;
+        const int mo = (int)((obase + (unsigned long long)go) & 3);
+        const int b0 = 4 * k - mo;  // segment byte index of this word's byte 0
+        if (b0 >= segb || b0 + 3 < 0) continue;
+        const uint32_t w = lout[r * HP_OUT + k];
+        uint8_t* dst = out + go + b0;
+        if (b0 >= 0 && b0 + 4 <= segb) *reinterpret_cast<uint32_t*>(dst) = w;
+        else
+            for (int b = 0; b < 4; ++b)
+                if (b0 + b >= 0 && b0 + b < segb) dst[b] = (uint8_t)(w >> (8 * b));
+    }
+}
+
+// Vertical pass, tiled (<= VK <= VKMAX taps): one workgroup = VT_R output rows x VT_XB row bytes.  The input rows those outputs
+// touch are staged in LDS by fill_rows() (lds_rows rows are allocated: the largest span of any row group + VK of slack, so the
+// straight-line tap loop may read rows past the span with zero coefficients), the VT_R coefficient rows are staged too; every
+// thread owns one ALIGNED 4-byte word of each output row and, per tap, reads the 4 input bytes above it as two LDS words +
+// v_alignbyte.
+constexpr int VT_XB = 1024, VT_R = 8, VKMAX = 16, VT_PAD = 4;
+constexpr int VT_NW = (VT_XB + 2 * VT_PAD) / 4 + 1, VT_PITCH = VT_NW + 2;
+template <int VK>
+__global__ __launch_bounds__(256) void resample_v_tile_kernel(const uint8_t* in, uint8_t* out, const int* bounds, const int* kk, int ksize, int H,
+                                                              int rowbytes, int Ho, long long total_in) {
+    extern __shared__ uint32_t lds[];   // [lds_rows][VT_PITCH]
+    __shared__ int kl[VT_R * VK];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z, yo0 = blockIdx.y * VT_R, x0 = blockIdx.x * VT_XB;
+    const int nyo = min(VT_R, Ho - yo0);
+    for (int i = tid; i < VT_R * VK; i += 256) {
+        const int rr = i / VK, j = i - rr * VK;
+        kl[i] = (rr < nyo && j < ksize) ? kk[(size_t)(yo0 + rr) * ksize + j] : 0;
+    }
+    const int in_lo = bounds[2 * yo0];
+    const int in_hi = bounds[2 * (yo0 + nyo - 1)] + bounds[2 * (yo0 + nyo - 1) + 1];  // exclusive
+    const uintptr_t ibase = reinterpret_cast<uintptr_t>(in), obase = reinterpret_cast<uintptr_t>(out);
+    const long long g0 = ((long long)n * H + in_lo) * rowbytes + x0 - VT_PAD;
+    fill_rows(lds, VT_PITCH, VT_NW, in, g0, rowbytes, in_hi - in_lo, 0, in_hi - in_lo, total_in, WordIdentity());
+    __syncthreads();
+    const int m0 = (int)((ibase + (unsigned long long)g0) & 3), dm = rowbytes & 3;
+    for (int rr = 0; rr < nyo; ++rr) {
+        const int yo = yo0 + rr;
+        const int lo = bounds[2 * yo] - in_lo;
+        const long long go = ((long long)n * Ho + yo) * rowbytes + x0;
+        const int mo = (int)((obase + (unsigned long long)go) & 3);
+        const int ew = x0 - mo + 4 * tid;
+        if (ew >= rowbytes || ew + 3 < 0) continue;
+        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
+#pragma unroll
+        for (int j = 0; j < VK; ++j) {  // straight-line: taps beyond the row's count have coefficient 0
+            const int r = lo + j;
+            const int off = ((m0 + r * dm) & 3) - mo + 4 * tid + VT_PAD;
+            const uint32_t* lr = lds + r * VT_PITCH + (off >> 2);
+            const uint32_t w = __builtin_amdgcn_alignbyte(lr[1], lr[0], (uint32_t)(off & 3));
+            const int kj = kl[rr * VK + j];
+            s0 += (int)(w & 0xff) * kj; s1 += (int)((w >> 8) & 0xff) * kj; s2 += (int)((w >> 16) & 0xff) * kj; s3 += (int)(w >> 24) * kj;
+        }
+        s0 >>= PRECISION_BITS; s1 >>= PRECISION_BITS; s2 >>= PRECISION_BITS; s3 >>= PRECISION_BITS;
+        const uint32_t res = (uint32_t)(s0 < 0 ? 0 : (s0 > 255 ? 255 : s0)) | ((uint32_t)(s1 < 0 ? 0 : (s1 > 255 ? 255 : s1)) << 8) |
+                             ((uint32_t)(s2 < 0 ? 0 : (s2 > 255 ? 255 : s2)) << 16) | ((uint32_t)(s3 < 0 ? 0 : (s3 > 255 ? 255 : s3)) << 24);
+        uint8_t* dst = out + go - mo + 4 * tid;
+        if (ew >= 0 && ew + 4 <= rowbytes) *reinterpret_cast<uint32_t*>(dst) = res;
+        else
+            for (int j = 0; j < 4; ++j)
+                if (ew + j >= 0 && ew + j < rowbytes) dst[j] = (uint8_t)(res >> (8 * j));
+    }
+}
+
 __global__ __launch_bounds__(256) void gray_sum_kernel(const uint8_t* img, unsigned long long* sums, int HW) {
     __shared__ unsigned long long part[4];
     const int n = blockIdx.y;
@@ -129,60 +289,96 @@ __device__ __forceinline__ uint8_t blend_u8(int deg, int v, float alpha) {
     return (uint8_t)t;
 }
 
-// contrast: 4 bytes per thread (the image size H*W*3 need not be a multiple of 4: the tail is done bytewise)
-__global__ void contrast_kernel(const uint8_t* img, uint8_t* out, const unsigned long long* sums, int HW, float alpha) {
-    const int n = blockIdx.y;
-    const int mean = (int)((double)sums[n] / (double)HW + 0.5);
-    const unsigned total = (unsigned)HW * 3u;
-    const uint8_t* p = img + (size_t)n * total;
-    uint8_t* o = out + (size_t)n * total;
-    const unsigned mis = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);          // leading bytes until 4-byte alignment
-    const unsigned head = mis ? 4u - mis : 0u;
-    const bool same = (reinterpret_cast<uintptr_t>(o) & 3u) == mis;                // in/out equally aligned (they are: same layout)
-    const unsigned words = same && total > head ? (total - head) / 4u : 0u;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) {
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(p + head + 4u * i);
-        const uint32_t r0 = blend_u8(mean, (int)(w & 0xff), alpha), r1 = blend_u8(mean, (int)((w >> 8) & 0xff), alpha);
-        const uint32_t r2 = blend_u8(mean, (int)((w >> 16) & 0xff), alpha), r3 = blend_u8(mean, (int)(w >> 24), alpha);
-        *reinterpret_cast<uint32_t*>(o + head + 4u * i) = r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
-    }
-    if (blockIdx.x == 0) {
-        for (unsigned i = threadIdx.x; i < head && i < total; i += blockDim.x) o[i] = blend_u8(mean, p[i], alpha);
-        for (unsigned i = head + 4u * words + threadIdx.x; i < total; i += blockDim.x) o[i] = blend_u8(mean, p[i], alpha);
-    }
+// Fused contrast + sharpness.  One workgroup = EN_R rows x EN_XB row bytes.  The contrast-blended bytes of the EN_R + 2 rows
+// (8 bytes of apron left and right) are built ONCE in LDS from aligned 4-byte global loads — every LDS row keeps its global
+// word alignment, so the fill is load -> 4 blends -> ds_write_b32 — and the 3x3 SMOOTH blend then reads 12-byte windows at
+// arbitrary byte offsets (4 aligned LDS words + v_alignbyte).  Each thread owns one ALIGNED 4-byte word of the output row
+// (rows of W*3 bytes are not word aligned in general: the strip of a row is shifted left by the row's misalignment), so
+// the result is stored with one dword store; the first / last word of a row is stored bytewise.
+// Arithmetic order is Pillow's (ImageFilter.SMOOTH: row y+1, y, y-1, left to right, + 0.5 offset, float32), see
+// /root/reference/backend/utils/image_preprocessing.py:132-158.
+constexpr int EN_XB = 1024, EN_R = 8, EN_PAD = 8;
+constexpr int EN_NW = (EN_XB + 2 * EN_PAD) / 4 + 1;  // words per LDS row (misalignment <= 3 bytes)
+constexpr int EN_PITCH = EN_NW + 3;
+
+__device__ __forceinline__ uint32_t blend_u8x4(int deg, uint32_t w, float alpha) {
+    return (uint32_t)blend_u8(deg, (int)(w & 0xff), alpha) | ((uint32_t)blend_u8(deg, (int)((w >> 8) & 0xff), alpha) << 8) |
+           ((uint32_t)blend_u8(deg, (int)((w >> 16) & 0xff), alpha) << 16) | ((uint32_t)blend_u8(deg, (int)(w >> 24), alpha) << 24);
 }
 
-// sharpen: grid (x-chunks, rows, images): no 64-bit index arithmetic, one output byte per thread, 9 neighbour bytes
-__global__ void sharpen_kernel(const uint8_t* img, uint8_t* out, int H, int W, float alpha) {
-    const int n = blockIdx.z, y = blockIdx.y;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;   // byte inside the row: x*3 + c
+struct ContrastWord {
+    int mean; float alpha;
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return blend_u8x4(mean, w, alpha); }
+};
+
+__global__ __launch_bounds__(256) void enhance_kernel(const uint8_t* img, uint8_t* out, const unsigned long long* sums, int H, int W,
+                                                      float alpha_c, float alpha_s, long long total_bytes) {
+    __shared__ uint32_t lds[(EN_R + 2) * EN_PITCH];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z, yb = blockIdx.y * EN_R, e0 = blockIdx.x * EN_XB;
     const int rowb = W * 3;
-    if (e >= rowb) return;
-    const size_t base = ((size_t)n * H + y) * rowb;
-    const uint8_t* r0 = img + base + e;
-    const int v = r0[0];
-    int deg = v;
-    if (e >= 3 && e < rowb - 3 && y > 0 && y < H - 1) {
-        const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
-        const uint8_t* r1 = r0 + rowb;
-        const uint8_t* r_1 = r0 - rowb;
-        float ss = 0.5f;
-        // Pillow order: row y+1 (kernel[0..2]), row y (kernel[3..5]), row y-1 (kernel[6..8]); left-to-right adds
-        float a = __fmul_rn((float)r1[-3], k1);
-        a = __fadd_rn(a, __fmul_rn((float)r1[0], k1));
-        a = __fadd_rn(a, __fmul_rn((float)r1[3], k1));
-        ss = __fadd_rn(ss, a);
-        a = __fmul_rn((float)r0[-3], k1);
-        a = __fadd_rn(a, __fmul_rn((float)r0[0], k5));
-        a = __fadd_rn(a, __fmul_rn((float)r0[3], k1));
-        ss = __fadd_rn(ss, a);
-        a = __fmul_rn((float)r_1[-3], k1);
-        a = __fadd_rn(a, __fmul_rn((float)r_1[0], k1));
-        a = __fadd_rn(a, __fmul_rn((float)r_1[3], k1));
-        ss = __fadd_rn(ss, a);
-        deg = ss <= 0.f ? 0 : (ss >= 255.f ? 255 : (int)ss);
+    const int mean = (int)((double)sums[n] / (double)((long long)H * W) + 0.5);
+    const uintptr_t ibase = reinterpret_cast<uintptr_t>(img), obase = reinterpret_cast<uintptr_t>(out);
+    const long long g0 = ((long long)n * H + yb - 1) * rowb + e0 - EN_PAD;  // flat byte index of LDS row 0's byte 0 (image row yb - 1)
+    const int rlo = yb == 0 ? 1 : 0, rhi = min(EN_R + 2, H - yb + 1);       // LDS rows whose image row exists
+    fill_rows(lds, EN_PITCH, EN_NW, img, g0, rowb, EN_R + 2, rlo, rhi, total_bytes, ContrastWord{mean, alpha_c});
+    __syncthreads();
+
+    for (int rr = 0; rr < EN_R; ++rr) {
+        const int y = yb + rr;
+        if (y >= H) break;
+        const long long go = ((long long)n * H + y) * rowb + e0;
+        const int mo = (int)((obase + (unsigned long long)go) & 3);
+        const int ew = e0 - mo + 4 * tid;  // row-relative byte index of this thread's aligned output word
+        if (ew >= rowb || ew + 3 < 0) continue;
+        uint32_t win[3][3];  // [row y-1, y, y+1][12 bytes starting at row byte ew - 3]
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int yy = y - 1 + d;
+            const long long g = ((long long)n * H + yy) * rowb + e0 - EN_PAD;
+            const int m = (int)((ibase + (unsigned long long)g) & 3);
+            const int off = m - mo + 4 * tid + (EN_PAD - 3);
+            const int q = off >> 2;
+            const uint32_t sh = (uint32_t)(off & 3);
+            const uint32_t* lr = lds + (rr + d) * EN_PITCH + q;
+            const uint32_t w0 = lr[0], w1 = lr[1], w2 = lr[2], w3 = lr[3];
+            win[d][0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+            win[d][1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            win[d][2] = __builtin_amdgcn_alignbyte(w3, w2, sh);
+        }
+        const bool yin = y > 0 && y < H - 1;
+        uint32_t res = 0;
+#define WB(d_, p_) ((float)((win[d_][(p_) >> 2] >> (8 * ((p_) & 3))) & 0xffu))
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = ew + j;
+            const int v = (int)((win[1][(j + 3) >> 2] >> (8 * ((j + 3) & 3))) & 0xffu);
+            // straight-line: the smoothed value is computed for every byte and selected for interior pixels only
+            const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
+            float ss = 0.5f;
+            float a = __fmul_rn(WB(2, j), k1);
+            a = __fadd_rn(a, __fmul_rn(WB(2, j + 3), k1));
+            a = __fadd_rn(a, __fmul_rn(WB(2, j + 6), k1));
+            ss = __fadd_rn(ss, a);
+            a = __fmul_rn(WB(1, j), k1);
+            a = __fadd_rn(a, __fmul_rn(WB(1, j + 3), k5));
+            a = __fadd_rn(a, __fmul_rn(WB(1, j + 6), k1));
+            ss = __fadd_rn(ss, a);
+            a = __fmul_rn(WB(0, j), k1);
+            a = __fadd_rn(a, __fmul_rn(WB(0, j + 3), k1));
+            a = __fadd_rn(a, __fmul_rn(WB(0, j + 6), k1));
+            ss = __fadd_rn(ss, a);
+            const int sm = ss <= 0.f ? 0 : (ss >= 255.f ? 255 : (int)ss);
+            const int deg = (yin && e >= 3 && e < rowb - 3) ? sm : v;
+            res |= (uint32_t)blend_u8(deg, v, alpha_s) << (8 * j);
+        }
+#undef WB
+        uint8_t* dst = out + go - mo + 4 * tid;
+        if (ew >= 0 && ew + 4 <= rowb) *reinterpret_cast<uint32_t*>(dst) = res;
+        else
+            for (int j = 0; j < 4; ++j)
+                if (ew + j >= 0 && ew + j < rowb) dst[j] = (uint8_t)(res >> (8 * j));
     }
-    out[base + e] = blend_u8(deg, v, alpha);
 }
 
 inline int grid_for(size_t total) {
@@ -237,19 +433,46 @@ void lanczos_coeffs(int in_size, int out_size, int* ksize_out, std::vector<int>*
 }
 
 hipError_t resample_launch(const uint8_t* in, uint8_t* out, const int* bounds_dev, const int* kk_dev, int ksize, int N, int H, int W, int C,
-                           int out_len, int axis, hipStream_t st) {
+                           int out_len, int axis, const int* bounds_host, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resample_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
     if (axis == 0) {
         const size_t lds = ((size_t)W * C + 8 + 3) / 4 * 4;
         if (lds > 150 * 1024) return hipErrorInvalidValue;
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resample_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            if (e != hipSuccess) return e;
-            attr = true;
+        bool fast = C == 3 && ksize <= HKMAX && bounds_host != nullptr;
+        for (int x0 = 0; fast && x0 < out_len; x0 += HX) {
+            const int x1 = (x0 + HX < out_len ? x0 + HX : out_len) - 1;
+            if (bounds_host[2 * x1] + bounds_host[2 * x1 + 1] - bounds_host[2 * x0] > HPXMAX) fast = false;
         }
-        hipLaunchKernelGGL(resample_h_kernel, dim3(N * H), dim3(256), lds, st, in, out, bounds_dev, kk_dev, ksize, H, W, C, out_len, (size_t)N * H * W * C);
+        if (fast) {
+            const int rows = N * H;
+            const dim3 grid((out_len + HX - 1) / HX, (rows + HR - 1) / HR);
+            if (ksize <= 9) hipLaunchKernelGGL(resample_h_rgb_kernel<9>, grid, dim3(256), 0, st, in, out, bounds_dev, kk_dev, ksize, rows, W, out_len, (long long)N * H * W * C);
+            else hipLaunchKernelGGL(resample_h_rgb_kernel<HKMAX>, grid, dim3(256), 0, st, in, out, bounds_dev, kk_dev, ksize, rows, W, out_len, (long long)N * H * W * C);
+        } else {
+            hipLaunchKernelGGL(resample_h_kernel, dim3(N * H), dim3(256), lds, st, in, out, bounds_dev, kk_dev, ksize, H, W, C, out_len, (size_t)N * H * W * C);
+        }
     } else {
         const int rowbytes = W * C;
+        // tiled kernel when the taps fit its unrolled loop and the largest input-row span of a group of VT_R output rows fits LDS
+        int span = 0;
+        for (int y0 = 0; bounds_host != nullptr && y0 < out_len; y0 += VT_R) {
+            const int y1 = (y0 + VT_R < out_len ? y0 + VT_R : out_len) - 1;
+            const int sp = bounds_host[2 * y1] + bounds_host[2 * y1 + 1] - bounds_host[2 * y0];
+            if (sp > span) span = sp;
+        }
+        const int vk = ksize <= 9 ? 9 : VKMAX;
+        const size_t lds_bytes = (size_t)(span + vk) * VT_PITCH * 4;
+        if (bounds_host != nullptr && ksize <= VKMAX && lds_bytes <= 60 * 1024) {
+            const dim3 grid((rowbytes + 3 + VT_XB - 1) / VT_XB, (out_len + VT_R - 1) / VT_R, N);
+            if (vk == 9) hipLaunchKernelGGL(resample_v_tile_kernel<9>, grid, dim3(256), lds_bytes, st, in, out, bounds_dev, kk_dev, ksize, H, rowbytes, out_len, (long long)N * H * rowbytes);
+            else hipLaunchKernelGGL(resample_v_tile_kernel<VKMAX>, grid, dim3(256), lds_bytes, st, in, out, bounds_dev, kk_dev, ksize, H, rowbytes, out_len, (long long)N * H * rowbytes);
+            return hipGetLastError();
+        }
         const bool a4 = rowbytes % 4 == 0 && (reinterpret_cast<uintptr_t>(in) % 4 == 0) && (reinterpret_cast<uintptr_t>(out) % 4 == 0);
         const bool a2 = rowbytes % 2 == 0 && (reinterpret_cast<uintptr_t>(in) % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 2 == 0);
         if (a4) hipLaunchKernelGGL(resample_v_kernel<4>, dim3(N * out_len), dim3(256), 0, st, in, out, bounds_dev, kk_dev, ksize, H, rowbytes, out_len);
@@ -267,7 +490,9 @@ hipError_t enhance_launch(const uint8_t* img, uint8_t* tmp, uint8_t* out, unsign
     int gx = (HW + 255) / 256;
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(gray_sum_kernel, dim3(gx > 64 ? 64 : gx, N), dim3(256), 0, st, img, sums_dev, HW);
-    hipLaunchKernelGGL(contrast_kernel, dim3(gx, N), dim3(256), 0, st, img, tmp, sums_dev, HW, contrast);
-    hipLaunchKernelGGL(sharpen_kernel, dim3((W * 3 + 255) / 256, H, N), dim3(256), 0, st, tmp, out, H, W, sharpness);
+    (void)tmp;
+    const int rowb = W * 3;
+    hipLaunchKernelGGL(enhance_kernel, dim3((rowb + 3 + EN_XB - 1) / EN_XB, (H + EN_R - 1) / EN_R, N), dim3(256), 0, st, img, out, sums_dev, H, W,
+                       contrast, sharpness, (long long)N * H * rowb);
     return hipGetLastError();
 }

@@ -61,3 +61,36 @@ def test_batch_and_edge_sizes_vs_oracle(engine):
     flat = np.full((1, 40, 40, 3), 255, np.uint8)                                          # saturated page: clipping branches
     assert np.array_equal(engine.enhance(torch.from_numpy(flat).cuda(), 1.2, 1.1).cpu().numpy()[0],
                           P.enhance_sharpness(P.enhance_contrast(flat[0], 1.2), 1.1))
+
+
+@pytest.mark.parametrize("shape", [(3, 1, 5), (2, 2, 6), (3, 3, 7), (3, 9, 8), (2, 17, 345), (2, 11, 683), (3, 21, 342), (1, 5, 1369)])
+def test_enhance_alignment_cases_vs_oracle(engine, shape):
+    """Rows of W*3 bytes start at every 4-byte misalignment; batches make image starts misaligned too; strips > 1024 bytes."""
+    from oracle import preprocess as P
+    n, h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    x = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    got = engine.enhance(torch.from_numpy(x).cuda(), 1.2, 1.1).cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(got[k], P.enhance_sharpness(P.enhance_contrast(x[k], 1.2), 1.1)), (shape, k)
+    # a view that starts at an odd byte address (sub-tensor of a larger allocation)
+    big = torch.from_numpy(np.concatenate([np.zeros(1, np.uint8), x.reshape(-1)])).cuda()
+    view = big[1:].view(n, h, w, 3)
+    got2 = engine.enhance(view, 1.2, 1.1).cpu().numpy()
+    assert np.array_equal(got2, got)
+
+
+@pytest.mark.parametrize("case", [(2, 37, 61, 29, 50), (1, 64, 343, 55, 300), (3, 50, 90, 41, 77), (1, 200, 130, 20, 13), (2, 33, 47, 70, 99),
+                                  (1, 19, 1400, 17, 1250)])
+def test_resize_alignment_cases_vs_oracle(engine, case):
+    """Both passes at every row misalignment, batches, the LDS-tiled and the fallback (strong down-scale) vertical kernels."""
+    from oracle import preprocess as P
+    n, h, w, oh, ow = case
+    rng = np.random.default_rng(h * 977 + w)
+    x = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    got = engine.resize_lanczos(torch.from_numpy(x).cuda(), oh, ow).cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(got[k], P.resize_lanczos(x[k], ow, oh)), (case, k)
+    big = torch.from_numpy(np.concatenate([np.zeros(3, np.uint8), x.reshape(-1)])).cuda()
+    got2 = engine.resize_lanczos(big[3:].view(n, h, w, 3), oh, ow).cpu().numpy()
+    assert np.array_equal(got2, got)
