@@ -25,7 +25,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.f);
-        case ACT_HSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f;
+        case ACT_HSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);  // x * relu6(x + 3) * fp32(1/6), no division
         case ACT_HSIGMOID: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
         case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         default: return v;

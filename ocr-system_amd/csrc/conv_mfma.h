@@ -52,6 +52,3 @@ bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cf
 hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t stream);
 const char* conv_kernel_name(const ConvKernelCfg& cfg);
 
-// A-stationary 1x1 / GEMM kernel (conv1x1.hip): same packed weights as conv_mfma with bn == 64.
-bool conv1x1_supported(const ConvKernelCfg& cfg, const ConvParams& p);
-hipError_t conv1x1_launch(ConvParams p, long long total_px, hipStream_t stream);

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(NW * 64, ((DB == 1 || DB == 2) ? NW / 4 : (BN <= 64
         _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                       \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) { const float v = acc[mt][nt][j]; acc[mt][nt][j] = (expr); }
     if (p.act == ACT_RELU) { FOR_ALL_ACC(fmaxf(v, 0.f)) }
-    else if (p.act == ACT_HSWISH) { FOR_ALL_ACC(v * fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f) }
+    else if (p.act == ACT_HSWISH) { FOR_ALL_ACC(v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f)) }
     else if (p.act == ACT_SIGMOID) { FOR_ALL_ACC(1.f / (1.f + expf(-v))) }
     else if (p.act == ACT_HSIGMOID) { FOR_ALL_ACC(fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f)) }
 #undef FOR_ALL_ACC

@@ -236,18 +236,14 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, st));
     }
-    // conv1x1.hip (A-stationary, all channel tiles in one workgroup) measured SLOWER than one workgroup per channel tile
-    // on every DBNet 1x1 layer (fpn.in2 0.80 vs 0.68 ms / 16 pages): it is an opt-in experiment, not the default.
-    static const bool want1x1 = getenv("LUMINA_CONV1X1") != nullptr;
     static const bool no_big = getenv("LUMINA_CONV_NO_BIG") != nullptr;
-    const bool use1x1 = want1x1 && conv1x1_supported(L.cfg, p);
     // 16x32 tiles (less LDS and L2 traffic per MFMA) once they still give >= 2 workgroups per CU on all 256 CUs twice over
     const long long big_blocks = (long long)p.N * ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32) * ((L.cout + L.cfg.bn - 1) / L.cfg.bn);
     static const long long big_min = getenv("LUMINA_CONV_BIG_MIN") ? atoll(getenv("LUMINA_CONV_BIG_MIN")) : 1024;
     const bool use_big = !no_big && !flat && L.wpk_big != nullptr && big_blocks >= big_min;
     ConvKernelCfg cfg = L.cfg;
     if (use_big) { cfg = L.cfg_big; p.wpk = L.wpk_big; }
-    hipError_t e = use1x1 ? conv1x1_launch(p, flat ? (long long)p.pix_limit : (long long)p.N * p.H * p.W, st) : conv_launch(cfg, p, st);
+    hipError_t e = conv_launch(cfg, p, st);
     if (e != hipSuccess) return locr_fail(eng, L.name.c_str(), hipGetErrorString(e));
     if (eng->time_convs) {
         HIPCHK(hipEventRecord(e1, st));
@@ -257,7 +253,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         // algorithmic HBM bytes: input once + output once (+ residual) + weights once
         eng->conv_bytes.push_back(2.0 * ((double)x.elems() + px * (out_mode == OUT_CONVT && p.fuse_w ? 4.0 : (double)L.cout) * (out_mode == OUT_UPSAMPLE ? (double)(1 << (2 * up_shift)) : 1.0) + (res ? px * (double)L.cout / (double)(1 << (2 * res_shift)) : 0.0) + (double)L.ks * L.ks * L.cin * L.cout));
         eng->conv_names.push_back(L.name);
-        eng->conv_kernels.push_back(use1x1 ? "conv1x1_astat<bn64>" : conv_kernel_name(cfg));
+        eng->conv_kernels.push_back(conv_kernel_name(cfg));
     }
     return 0;
 }

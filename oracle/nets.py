@@ -36,7 +36,7 @@ def _act(x: torch.Tensor, act: str) -> torch.Tensor:
     if act == "relu":
         return torch.relu(x)
     if act == "hswish":
-        return x * torch.clamp(x + 3.0, 0.0, 6.0) / 6.0
+        return x * torch.clamp(x + 3.0, 0.0, 6.0) * (1.0 / 6.0)  # multiply by fp32(1/6): the engine's definition (csrc/common.h apply_act)
     if act == "hsigmoid":  # PaddleOCR SE: slope 0.2, offset 0.5
         return torch.clamp(0.2 * x + 0.5, 0.0, 1.0)
     if act == "sigmoid":
