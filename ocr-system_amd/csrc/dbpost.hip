@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void comp_box_kernel(const bf16_t* prob, const
                                                        int* valid_tmp, int Hp, int Wp, int vh, int vw, int maxc, size_t seg_cap,
                                                        float box_thresh, float unclip_ratio, int min_size) {
     __shared__ int2 s_hull[HULL_LDS];
+    __shared__ int s_ext[HULL_LDS];  // row minima [0, HULL_LDS/2) and maxima [HULL_LDS/2, HULL_LDS) of the component
     __shared__ Cand s_cand[4];
     __shared__ unsigned long long s_sum[4], s_cnt[4];
     __shared__ int s_nl, s_nr, s_nh;
@@ -248,6 +249,12 @@ __global__ __launch_bounds__(256) void comp_box_kernel(const bf16_t* prob, const
     const int* rmax = rowmax + seg;
     const int rows = y1 - y0 + 1;
     int2* hull = (2 * rows <= HULL_LDS) ? s_hull : hullbuf + 2 * seg;
+    // the per-row extremes are fetched by the whole workgroup (coalesced, one latency) so that the two serial chain builders
+    // below walk LDS, not global memory (one dependent global load per row otherwise)
+    const bool ext_lds = rows <= HULL_LDS / 2;
+    if (ext_lds)
+        for (int r = tid; r < rows; r += 256) { s_ext[r] = rmin[r]; s_ext[HULL_LDS / 2 + r] = rmax[r]; }
+    __syncthreads();
     // ---- hull: thread 0 builds the left chain in hull[0..], thread 64 (another wave) the right chain in hull[rows..] ----
     if (tid == 0 || tid == 64) {
         const bool left = tid == 0;
@@ -255,7 +262,8 @@ __global__ __launch_bounds__(256) void comp_box_kernel(const bf16_t* prob, const
         int nc = 0;
         for (int t = 0; t < rows; ++t) {
             const int r = left ? t : rows - 1 - t;
-            const int2 p = make_int2(left ? rmin[r] : rmax[r], y0 + r);
+            const int ex = ext_lds ? s_ext[(left ? 0 : HULL_LDS / 2) + r] : (left ? rmin[r] : rmax[r]);
+            const int2 p = make_int2(ex, y0 + r);
             while (nc >= 2) {
                 const int2 o = ch[nc - 2], a = ch[nc - 1];
                 const long long cr = (long long)(a.x - o.x) * (p.y - o.y) - (long long)(a.y - o.y) * (p.x - o.x);

@@ -39,27 +39,46 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
         constexpr int WPR = (SEG + 3) / 4 + 1;            // aligned words that can cover it (50)
         const long long img_off = (long long)n_img * p.H * p.W * 3;   // addresses are aligned relative to p.x (allocation base), not to this image
         const long long all_bytes = (long long)p.N * p.H * p.W * 3;
-        for (int i = tid; i < HH * WPR; i += 256) {
+        constexpr int NIT = (HH * WPR + 255) / 256;
+        // phase 1: all aligned words of this thread are requested back to back (one memory latency, not one per item)
+        uint32_t word[NIT];
+        long long a0s[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + 256 * u;
+            const int hy = i / WPR, wi = i - hy * WPR;
+            const int iy = iy0 + hy;
+            word[u] = 0;
+            a0s[u] = 0;
+            if (i < HH * WPR && iy >= 0 && iy < vh) {
+                const long long seg0 = img_off + ((long long)iy * p.W + ix0) * 3;   // byte offset of the segment start (may be < 0 at x = -1)
+                const long long a0 = (seg0 & ~3ll) + 4ll * wi;                // aligned word this thread fetches
+                a0s[u] = a0;
+                if (a0 >= 0 && a0 + 4 <= all_bytes) word[u] = *reinterpret_cast<const uint32_t*>(p.x + a0);
+                else for (int b = 0; b < 4; ++b) if (a0 + b >= 0 && a0 + b < all_bytes) word[u] |= (uint32_t)p.x[a0 + b] << (8 * b);
+            }
+        }
+        // phase 2: normalise and scatter the bytes of each word into the bf16 halo
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + 256 * u;
+            if (i >= HH * WPR) break;
             const int hy = i / WPR, wi = i - hy * WPR;
             const int iy = iy0 + hy;
             if (iy < 0 || iy >= vh) {                      // whole row outside the page: zeros (normalised space)
                 for (int b = 0; b < 4; ++b) { const int e = wi * 4 + b; if (e < SEG) halo[hy * ROW + e] = 0; }
                 continue;
             }
-            const long long seg0 = img_off + ((long long)iy * p.W + ix0) * 3;   // byte offset of the segment start (may be < 0 at x = -1)
-            const long long a0 = (seg0 & ~3ll) + 4ll * wi;                // aligned word this thread fetches
-            uint32_t word = 0;
-            if (a0 >= 0 && a0 + 4 <= all_bytes) word = *reinterpret_cast<const uint32_t*>(p.x + a0);
-            else for (int b = 0; b < 4; ++b) if (a0 + b >= 0 && a0 + b < all_bytes) word |= (uint32_t)p.x[a0 + b] << (8 * b);
+            const long long seg0 = img_off + ((long long)iy * p.W + ix0) * 3;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const long long e = a0 + b - seg0;          // element index inside the row segment
+                const long long e = a0s[u] + b - seg0;          // element index inside the row segment
                 if (e < 0 || e >= SEG) continue;
                 const int hx = (int)e / 3, c = (int)e - hx * 3;
                 const int ix = ix0 + hx;
                 float v = 0.f;
                 if (ix >= 0 && ix < vw) {
-                    v = (float)((word >> (8 * b)) & 0xffu) * p.scale[c];
+                    v = (float)((word[u] >> (8 * b)) & 0xffu) * p.scale[c];
                     v = v + p.shift[c];
                 }
                 halo[hy * ROW + (int)e] = f32_to_bf16(v);
