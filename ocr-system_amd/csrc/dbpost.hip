@@ -347,17 +347,29 @@ __global__ __launch_bounds__(256) void comp_box_kernel(const bf16_t* prob, const
     unsigned long long sum = 0, cnt = 0;
     const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
     const bf16_t* pp = prob + (size_t)pg * Hp * Wp;
-    const bool axis = best.dy == 0 || best.dx == 0;  // axis-aligned rectangle: every pixel of the (tight) span is inside
-    for (int yy = by0 + wave; yy <= by1; yy += 4) {   // one wave per row: coalesced bf16 reads
-        const bf16_t* prow = pp + (size_t)yy * Wp;
-        for (int xx = bx0 + lane; xx <= bx1; xx += 64) {
-            const long long pd = (long long)xx * best.dx + (long long)yy * best.dy, pn = -(long long)xx * best.dy + (long long)yy * best.dx;
-            if (pd < best.mind || pd > best.maxd || pn < best.minn || pn > best.maxn) continue;
-            sum += (unsigned long long)(bf16_to_f32(prow[xx]) * 16777216.0f);
-            ++cnt;
+    // all 256 threads sweep the bounding span; 8 probability loads per thread are requested before the first inside-test
+    // (a load inside the divergent test costs one memory latency per pixel column)
+    const int npx = bw * bh;
+    for (int i0 = 0; i0 < npx; i0 += 256 * 8) {
+        float pv[8];
+        int px[8], py[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256 + tid;
+            const int ic = i < npx ? i : 0;
+            const int ry = ic / bw;
+            py[u] = i < npx ? by0 + ry : -1;
+            px[u] = bx0 + (ic - ry * bw);
+            pv[u] = bf16_to_f32(pp[(size_t)(by0 + ry) * Wp + px[u]]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long pd = (long long)px[u] * best.dx + (long long)py[u] * best.dy, pn = -(long long)px[u] * best.dy + (long long)py[u] * best.dx;
+            const bool in = py[u] >= 0 && pd >= best.mind && pd <= best.maxd && pn >= best.minn && pn <= best.maxn;
+            sum += in ? (unsigned long long)(pv[u] * 16777216.0f) : 0ull;
+            cnt += in ? 1ull : 0ull;
         }
     }
-    (void)axis; (void)bw; (void)bh;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { sum += (unsigned long long)shfl_xor_ll((long long)sum, m); cnt += (unsigned long long)shfl_xor_ll((long long)cnt, m); }
     if (lane == 0) { s_sum[wave] = sum; s_cnt[wave] = cnt; }
