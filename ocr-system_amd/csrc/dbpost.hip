@@ -10,7 +10,7 @@
 //   2 ccl_merge     per pixel: union-find (atomicMin) links to the row above (8-connectivity)
 //   3 ccl_compress  label = root = smallest linear index of the component (canonical)
 //   4 root_count / root_scan / root_assign : roots in raster order -> component id k < max_boxes
-//   5 comp_extent   per pixel: atomicMin/Max of the component's y range
+//   5 comp_extent   per run start: atomicMax of the component's bottom row (the top row is the root's row)
 //   6 seg_scan      per page: row-extreme segments; 7 row_extremes: per-row min/max x (atomics)
 //   8 comp_box      one wave per component: hull (monotone chains), rotating calipers over hull
 //                   edges (lanes = edges), fixed-point score (lanes = pixels), unclip, corner order
@@ -34,57 +34,85 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
     }
 }
 
-// ---- 1: one wave per (page,row) ----
-__global__ __launch_bounds__(64) void ccl_init_kernel(const bf16_t* prob, int* label, int Hp, int Wp, int vh, int vw, float thresh) {
-    const int row = blockIdx.x % Hp, pg = blockIdx.x / Hp, lane = threadIdx.x;
+// ---- 1: one wave per (page,row), four rows per workgroup; the row's probabilities are requested 8 chunks at a time ----
+__global__ __launch_bounds__(256) void ccl_init_kernel(const bf16_t* prob, int* label, int Hp, int Wp, int vh, int vw, float thresh, int rows_total) {
+    const int wrow = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wrow >= rows_total) return;
+    const int row = wrow % Hp, pg = wrow / Hp;
     const size_t base = ((size_t)pg * Hp + row) * Wp;
     int carry = -1;  // run start (x) continuing from the previous chunk, -1 = none
-    for (int x0 = 0; x0 < Wp; x0 += 64) {
-        const int x = x0 + lane;
-        const bool fg = x < vw && row < vh && bf16_to_f32(prob[base + x]) > thresh;
-        const unsigned long long m = __ballot(fg);
-        const unsigned long long below = (~m) & ((1ull << lane) - 1ull);  // background lanes below me
-        int start;
-        if (below) start = x0 + (63 - __clzll(below)) + 1;
-        else start = carry >= 0 ? carry : x0;
-        if (x < Wp) label[base + x] = fg ? (int)(row * Wp + start) : -1;
-        // carry for next chunk: if lane 63 is fg, its run start
-        const int s63 = __shfl(start, 63);
-        carry = (m >> 63) ? s63 : -1;
+    for (int xb = 0; xb < Wp; xb += 64 * 8) {
+        float pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int x = xb + u * 64 + lane;
+            pv[u] = bf16_to_f32(prob[base + (x < Wp ? x : Wp - 1)]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int x0 = xb + u * 64, x = x0 + lane;
+            if (x0 >= Wp) break;
+            const bool fg = x < vw && row < vh && pv[u] > thresh;
+            const unsigned long long m = __ballot(fg);
+            const unsigned long long below = (~m) & ((1ull << lane) - 1ull);  // background lanes below me
+            int start;
+            if (below) start = x0 + (63 - __clzll(below)) + 1;
+            else start = carry >= 0 ? carry : x0;
+            if (x < Wp) label[base + x] = fg ? (int)(row * Wp + start) : -1;
+            // carry for next chunk: if lane 63 is fg, its run start
+            const int s63 = __shfl(start, 63);
+            carry = (m >> 63) ? s63 : -1;
+        }
     }
 }
 
+// Per-pixel passes 2, 3, 5, 7: grid (chunks of 1024 pixels, pages); one thread = 4 consecutive pixels of a row (Wp % 4 == 0), so
+// the label image moves as 16-byte vectors, the index arithmetic is 32-bit and the (few) foreground quads do the real work.
+#define PIX4_DECODE                                                   \
+    const int per = Hp * Wp, pg = blockIdx.y;                         \
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;               \
+    if (i >= per) return;
+
 // ---- 2 ----
-__global__ void ccl_merge_kernel(int* label, int B, int Hp, int Wp, int vh, int vw) {
-    const size_t per = (size_t)Hp * Wp, total = per * B;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-        const int pg = (int)(g / per);
-        const int i = (int)(g - (size_t)pg * per);
-        const int y = i / Wp, x = i - y * Wp;
-        if (y == 0 || y >= vh || x >= vw) continue;
-        int* L = label + (size_t)pg * per;
-        if (L[i] < 0) continue;
-        const bool n = L[i - Wp] >= 0;
-        const bool w = x > 0 && L[i - 1] >= 0;
-        const bool nw = x > 0 && L[i - Wp - 1] >= 0;
-        const bool ne = x + 1 < vw && L[i - Wp + 1] >= 0;
-        if (n) { if (!(w && nw)) uf_union(L, i, i - Wp); }
+__global__ __launch_bounds__(256) void ccl_merge_kernel(int* label, int Hp, int Wp, int vh, int vw) {
+    PIX4_DECODE
+    int* L = label + (size_t)pg * per;
+    const int4 cv = *reinterpret_cast<const int4*>(L + i);
+    if ((cv.x & cv.y & cv.z & cv.w) < 0) return;  // four background pixels
+    const int y = i / Wp, x0 = i - y * Wp;
+    if (y == 0 || y >= vh) return;
+    // signs of the 6 labels above and of the one to the left (signs never change while roots are being merged)
+    const int4 uv = *reinterpret_cast<const int4*>(L + i - Wp);
+    const int ul = x0 > 0 ? L[i - Wp - 1] : -1, ur = x0 + 4 < Wp ? L[i - Wp + 4] : -1, wl = x0 > 0 ? L[i - 1] : -1;
+    const int cur[4] = {cv.x, cv.y, cv.z, cv.w};
+    const int up[6] = {ul, uv.x, uv.y, uv.z, uv.w, ur};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int x = x0 + e;
+        if (x >= vw || cur[e] < 0) continue;
+        const bool n = up[e + 1] >= 0;
+        const bool w = x > 0 && (e ? cur[e - 1] : wl) >= 0;
+        const bool nw = x > 0 && up[e] >= 0;
+        const bool ne = x + 1 < vw && up[e + 2] >= 0;
+        if (n) { if (!(w && nw)) uf_union(L, i + e, i + e - Wp); }
         else {
-            if (ne) uf_union(L, i, i - Wp + 1);
-            if (nw && !w) uf_union(L, i, i - Wp - 1);
+            if (ne) uf_union(L, i + e, i + e - Wp + 1);
+            if (nw && !w) uf_union(L, i + e, i + e - Wp - 1);
         }
     }
 }
 
 // ---- 3 ----
-__global__ void ccl_compress_kernel(int* label, int B, int Hp, int Wp) {
-    const size_t per = (size_t)Hp * Wp, total = per * B;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-        const int pg = (int)(g / per);
-        const int i = (int)(g - (size_t)pg * per);
-        int* L = label + (size_t)pg * per;
-        if (L[i] >= 0) L[i] = uf_find(L, i);
-    }
+__global__ __launch_bounds__(256) void ccl_compress_kernel(int* label, int Hp, int Wp) {
+    PIX4_DECODE
+    int* L = label + (size_t)pg * per;
+    int4 v = *reinterpret_cast<const int4*>(L + i);
+    if ((v.x & v.y & v.z & v.w) < 0) return;
+    if (v.x >= 0) v.x = uf_find(L, v.x);
+    if (v.y >= 0) v.y = uf_find(L, v.y);
+    if (v.z >= 0) v.z = uf_find(L, v.z);
+    if (v.w >= 0) v.w = uf_find(L, v.w);
+    *reinterpret_cast<int4*>(L + i) = v;
 }
 
 // ---- 4a: roots per row ----
@@ -130,29 +158,27 @@ __global__ __launch_bounds__(64) void root_assign_kernel(const int* label, const
             if (k < maxc) {
                 cid[base + x] = k;
                 comp_root[(size_t)pg * maxc + k] = row * Wp + x;
-                ymin[(size_t)pg * maxc + k] = 0x7fffffff;
-                ymax[(size_t)pg * maxc + k] = -1;
+                ymin[(size_t)pg * maxc + k] = row;  // the root is the smallest linear index of its component: its row IS the top row
+                ymax[(size_t)pg * maxc + k] = row;
             } else cid[base + x] = -1;
         }
         k0 += __popcll(m);
     }
 }
 // ---- 5 ----
-__global__ void comp_extent_kernel(const int* label, const int* cid, int* ymin, int* ymax, int B, int Hp, int Wp, int maxc) {
-    const size_t per = (size_t)Hp * Wp, total = per * B;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-        const int pg = (int)(g / per);
-        const int i = (int)(g - (size_t)pg * per);
-        const int r = label[g];
-        if (r < 0) continue;
-        const int x = i % Wp;
-        // only run starts contribute (one atomic per run)
-        if (x > 0 && label[g - 1] >= 0) continue;
-        const int k = cid[(size_t)pg * per + r];
+__global__ __launch_bounds__(256) void comp_extent_kernel(const int* label, const int* cid, int* ymax, int Hp, int Wp, int maxc) {
+    PIX4_DECODE
+    const int* L = label + (size_t)pg * per;
+    const int4 v = *reinterpret_cast<const int4*>(L + i);
+    if ((v.x & v.y & v.z & v.w) < 0) return;
+    const int y = i / Wp, x0 = i - y * Wp;
+    const int cur[5] = {x0 > 0 ? L[i - 1] : -1, v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (cur[e + 1] < 0 || cur[e] >= 0) continue;  // only run starts contribute (one atomic per run)
+        const int k = cid[(size_t)pg * per + cur[e + 1]];
         if (k < 0) continue;
-        const int y = i / Wp;
-        atomicMin(&ymin[(size_t)pg * maxc + k], y);
-        atomicMax(&ymax[(size_t)pg * maxc + k], y);
+        atomicMax(&ymax[(size_t)pg * maxc + k], y);  // (a plain read as pre-check measured 2x slower: it queues behind the line's atomics)
     }
 }
 // ---- 6: per page segment offsets (one wave) + init of the segments ----
@@ -177,23 +203,26 @@ __global__ void seg_init_kernel(int* rowmin, int* rowmax, size_t total) {
     }
 }
 // ---- 7 ----
-__global__ void row_extremes_kernel(const int* label, const int* cid, const int* ymin, const int* segoff, int* rowmin, int* rowmax,
-                                    int B, int Hp, int Wp, int vw, int maxc, size_t seg_cap) {
-    const size_t per = (size_t)Hp * Wp, total = per * B;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-        const int pg = (int)(g / per);
-        const int i = (int)(g - (size_t)pg * per);
-        const int r = label[g];
+__global__ __launch_bounds__(256) void row_extremes_kernel(const int* label, const int* cid, const int* ymin, const int* segoff, int* rowmin, int* rowmax,
+                                                           int Hp, int Wp, int vw, int maxc, size_t seg_cap) {
+    PIX4_DECODE
+    const int* L = label + (size_t)pg * per;
+    const int4 v = *reinterpret_cast<const int4*>(L + i);
+    if ((v.x & v.y & v.z & v.w) < 0) return;
+    const int y = i / Wp, x0 = i - y * Wp;
+    const int cur[6] = {x0 > 0 ? L[i - 1] : -1, v.x, v.y, v.z, v.w, x0 + 4 < Wp ? L[i + 4] : -1};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r = cur[e + 1], x = x0 + e;
         if (r < 0) continue;
-        const int y = i / Wp, x = i - y * Wp;
-        const bool start = !(x > 0 && label[g - 1] >= 0);
-        const bool end = !(x + 1 < vw && label[g + 1] >= 0);
+        const bool start = !(x > 0 && cur[e] >= 0);
+        const bool end = !(x + 1 < vw && cur[e + 2] >= 0);
         if (!start && !end) continue;
         const int k = cid[(size_t)pg * per + r];
         if (k < 0) continue;
-        const size_t s = (size_t)pg * seg_cap + segoff[(size_t)pg * (maxc + 1) + k] + (y - ymin[(size_t)pg * maxc + k]);
-        if (start) atomicMin(&rowmin[s], x);
-        if (end) atomicMax(&rowmax[s], x);
+        const size_t sg = (size_t)pg * seg_cap + segoff[(size_t)pg * (maxc + 1) + k] + (y - ymin[(size_t)pg * maxc + k]);
+        if (start) atomicMin(&rowmin[sg], x);
+        if (end) atomicMax(&rowmax[sg], x);
     }
 }
 
@@ -543,17 +572,18 @@ hipError_t dbpost_launch(const DbPostParams& p, void* workspace, hipStream_t st)
     float* score_tmp = static_cast<float*>(take((size_t)B * maxc * 4));
     int* valid_tmp = static_cast<int*>(take((size_t)B * maxc * 4));
 
-    const int gpix = grid_for(per * B);
-    hipLaunchKernelGGL(ccl_init_kernel, dim3(B * Hp), dim3(64), 0, st, p.prob, label, Hp, Wp, p.valid_h, p.valid_w, p.thresh);
-    hipLaunchKernelGGL(ccl_merge_kernel, dim3(gpix), dim3(256), 0, st, label, B, Hp, Wp, p.valid_h, p.valid_w);
-    hipLaunchKernelGGL(ccl_compress_kernel, dim3(gpix), dim3(256), 0, st, label, B, Hp, Wp);
+    if (Wp % 4 != 0 || per > 0x7fffffffull / 4) return hipErrorInvalidValue;
+    const dim3 gpix4((unsigned)((per / 4 + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(ccl_init_kernel, dim3((B * Hp + 3) / 4), dim3(256), 0, st, p.prob, label, Hp, Wp, p.valid_h, p.valid_w, p.thresh, B * Hp);
+    hipLaunchKernelGGL(ccl_merge_kernel, gpix4, dim3(256), 0, st, label, Hp, Wp, p.valid_h, p.valid_w);
+    hipLaunchKernelGGL(ccl_compress_kernel, gpix4, dim3(256), 0, st, label, Hp, Wp);
     hipLaunchKernelGGL(root_count_kernel, dim3(B * Hp), dim3(64), 0, st, label, rowcnt, Hp, Wp);
     hipLaunchKernelGGL(root_scan_kernel, dim3(B), dim3(64), 0, st, rowcnt, ncomp, Hp);
     hipLaunchKernelGGL(root_assign_kernel, dim3(B * Hp), dim3(64), 0, st, label, rowcnt, cid, comp_root, ymin, ymax, Hp, Wp, maxc);
-    hipLaunchKernelGGL(comp_extent_kernel, dim3(gpix), dim3(256), 0, st, label, cid, ymin, ymax, B, Hp, Wp, maxc);
+    hipLaunchKernelGGL(comp_extent_kernel, gpix4, dim3(256), 0, st, label, cid, ymax, Hp, Wp, maxc);
     hipLaunchKernelGGL(seg_scan_kernel, dim3(B), dim3(64), 0, st, ncomp, ymin, ymax, segoff, maxc);
     hipLaunchKernelGGL(seg_init_kernel, dim3(grid_for((size_t)B * seg_cap)), dim3(256), 0, st, rowmin, rowmax, (size_t)B * seg_cap);
-    hipLaunchKernelGGL(row_extremes_kernel, dim3(gpix), dim3(256), 0, st, label, cid, ymin, segoff, rowmin, rowmax, B, Hp, Wp, p.valid_w, maxc, seg_cap);
+    hipLaunchKernelGGL(row_extremes_kernel, gpix4, dim3(256), 0, st, label, cid, ymin, segoff, rowmin, rowmax, Hp, Wp, p.valid_w, maxc, seg_cap);
     hipLaunchKernelGGL(comp_box_kernel, dim3(B * maxc), dim3(256), 0, st, p.prob, ncomp, ymin, ymax, segoff, rowmin, rowmax, hull, box_tmp,
                        score_tmp, valid_tmp, Hp, Wp, p.valid_h, p.valid_w, maxc, seg_cap, p.box_thresh, p.unclip_ratio, p.min_size);
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(64), 0, st, box_tmp, score_tmp, valid_tmp, p.boxes, p.scores, p.counts, maxc);
