@@ -32,13 +32,13 @@ struct ConvParams {
     // before the contraction; gate_hw = pixels per image (the flat GEMM view hides the image boundaries)
     const bf16_t* gate;
     int gate_hw;
-    int dbg_skip;   // timing experiments only (LUMINA_CONV_DBG): 1 skip weight reloads, 2 skip halo reloads, 4 skip MFMAs (wrong results)
+    int dbg_skip;   // timing experiments only (LUMINA_CONV_DBG): 1 skip weight reloads, 2 skip halo reloads, 8 channel-blocked addressing (wrong results); 32 = staged epilogue everywhere
     int pix_limit;  // flat-GEMM mode (1x1): pixels >= pix_limit of an image are neither read nor written (0 = off)
     const bf16_t* zeros;  // >= 16 bytes of zeros in device memory (LDS-DMA variant: source of the out-of-image halo)
 };
 
 struct ConvKernelCfg {
-    int ks, stride, bn, ck, tw, nw;  // nw: waves per workgroup (4 = 8x32-pixel tile; 8 = 16x32, double-buffered LDS)
+    int ks, stride, bn, ck, tw, nw;  // nw selects the variant: 4 = 8x32-pixel tile; 5 = 16x32 tile (4 rows per wave); 6 = 16x32 tile fed by LDS-DMA
 };
 
 // Size in bytes of the packed weight image for (cout, ks, cin) under cfg.

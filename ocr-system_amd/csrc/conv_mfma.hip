@@ -5,22 +5,27 @@
 // the reference: /root/reference/backend/services/ocr_service.py:213-246 is a remote call).
 //
 // Structure (one 256-thread workgroup = 4 waves):
-//   * output tile  = TH x TW (=256) pixels  x  BN output channels; wave w owns pixel rows
-//     {2w, 2w+1} (two 32-pixel MFMA column tiles) x all BN/32 row tiles.
-//   * the K loop walks input-channel chunks of CK; per chunk the (TH-1)*S+KS x (TW-1)*S+KS
-//     input halo tile is staged ONCE in LDS and re-used by all KS*KS taps (im2col never touches
-//     HBM), together with the chunk's [tap][BN][CK] weight slab (pre-packed on the host in the
-//     exact LDS order, so its loads are fully coalesced).
-//   * LDS images are "plane" layouts: plane c holds the c-th 16-byte (8-channel) slice of every
-//     halo pixel / weight row, 16 B per entry.  A 32x32x16 MFMA fragment read (lane = pixel or
-//     cout, 8 consecutive k) is then a unit-stride ds_read_b128: conflict-free with no swizzle.
-//     The A plane stride is == 4 (mod 16) entries so the 4-lanes-per-pixel staging writes are
-//     conflict-free too.
-//   * orientation: D[cout][pixel] = W[cout][k] * X[k][pixel]  (weights are the MFMA A operand),
-//     so each lane ends up with 4 consecutive output channels of one pixel per accumulator
-//     quad -> packed 8-byte LDS staging writes -> 16-byte fully coalesced NHWC stores.
-//   * next chunk's global loads are issued into registers before the current chunk's MFMAs
-//     (async-stage split); two workgroups per CU (BN <= 64) overlap each other's barriers.
+//   * output tile  = TH x TW (=32) pixels  x  BN output channels; wave w owns MT pixel rows (MT 32-pixel MFMA column
+//     tiles) x all BN/32 row tiles.  Variants: MT = 2 (8x32 tile, any kernel size / stride) and MT = 4 (16x32 tile, 3x3 / s1
+//     with >= 64 input channels, picked per launch when the grid still fills the chip: less LDS and L2 traffic per MFMA).
+//   * the K loop walks input-channel chunks of CK; per chunk the (TH-1)*S+KS x (TW-1)*S+KS input halo tile is staged ONCE
+//     in LDS and re-used by all KS*KS taps (im2col never touches HBM), together with the chunk's [tap][BN][CK] weight slab
+//     (pre-packed on the host in the exact LDS order, so its loads are fully coalesced).
+//   * staging, DB == 0: global -> registers (issued before the current chunk's MFMAs) -> ds_write after the barrier, LDS
+//     images in "plane" layout: plane c holds the c-th 16-byte (8-channel) slice of every halo pixel / weight row.  A 32x32x16
+//     MFMA fragment read (lane = pixel or cout, 8 consecutive k) is a unit-stride ds_read_b128: conflict-free without
+//     swizzle; the A plane stride is == 4 (mod 16) entries so the 4-lanes-per-pixel staging writes are conflict-free too.
+//   * staging, DB == 3 (16x32 tile, CK = 16): global_load_lds_dwordx4 straight into a 2-deep LDS ring (no VGPR round trip, no
+//     ds_write pass, ONE barrier per chunk).  The LDS image is the lane-linear one a wave's DMA writes, [pixel][2 slices];
+//     with 16-channel chunks a fragment read is still one contiguous 1 KB.  Out-of-image halo pixels read a block of zeros.
+//   * fragment reads are software-pipelined one (tap, k-step) ahead of the MFMAs (sched_group_barrier interleave).
+//   * orientation: D[cout][pixel] = W[cout][k] * X[k][pixel]  (weights are the MFMA A operand), so each lane ends up with
+//     4 consecutive output channels of one pixel per accumulator quad.  Epilogue: bias + residual / top-down add + activation
+//     in registers, then either packed 8-byte LDS staging -> 16-byte coalesced stores (all output modes, fused DBHead tail),
+//     or, for plain NHWC output of the register-staged 3x3 kernels, v_permlane32_swap + 16-byte stores with no LDS/barrier.
+//   * two workgroups per CU (BN <= 64) overlap each other's barriers; block ids are remapped per XCD.
+// Measured dead ends (removed from the tree): 8-wave double-buffered LDS, 8-wave ping-pong groups,
+// A-stationary 1x1 kernel, persistent multi-tile LDS-DMA kernel, 64-channel chunks for 1x1.
 #include "conv_mfma.h"
 
 #include <cstdlib>
@@ -30,10 +35,8 @@ namespace {
 template <int KS, int S, int BN, int CK, int TW, int NW = 4, int DB = 0, int MT = 2>
 struct Cfg {
     static constexpr int NTHR = NW * 64;
-    static constexpr bool PP = (DB == 2);           // ping-pong: two 4-wave groups alternate compute / stage roles
     static constexpr bool DMA = (DB == 3);          // operands arrive by LDS-DMA (global_load_lds) into a 2-deep LDS ring
-    static constexpr int GTHR = PP ? 256 : NTHR;    // threads that cooperate on one LDS buffer
-    static constexpr int TH = (GTHR / 64) * MT;     // TW == 32: every wave owns MT pixel rows (MT 32-pixel MFMA column tiles)
+    static constexpr int TH = NW * MT;              // TW == 32: every wave owns MT pixel rows (MT 32-pixel MFMA column tiles)
     static constexpr int PAD = (KS == 3) ? 1 : 0;
     static constexpr int HH = (TH - 1) * S + KS;
     static constexpr int HW = (TW - 1) * S + KS;
@@ -56,13 +59,12 @@ struct Cfg {
     static constexpr int STAGE_PITCH = BN * 2 + 16;
     static constexpr int STAGE_BYTES = TH * TW * STAGE_PITCH;
     static constexpr int BUF_BYTES = A_BYTES + W_BYTES;
-    static constexpr int XCHG_BYTES = PP ? 256 * MT * NT * 16 * 4 : 0;  // fp32 accumulators of the second group
-    static constexpr int LDS_BYTES = (BUF_BYTES * (DB ? 2 : 1)) > (XCHG_BYTES + STAGE_BYTES) ? (BUF_BYTES * (DB ? 2 : 1)) : (XCHG_BYTES + STAGE_BYTES);
+    static constexpr int LDS_BYTES = (BUF_BYTES * (DMA ? 2 : 1)) > STAGE_BYTES ? (BUF_BYTES * (DMA ? 2 : 1)) : STAGE_BYTES;
     static_assert(!DMA || (CK == 16 && KS == 3 && S == 1), "DMA variant: 3x3 / stride 1 / 16-channel chunks");
     static constexpr int A_ITEMS = HH * HW * NPL;
-    static constexpr int AIT = (A_ITEMS + GTHR - 1) / GTHR;
+    static constexpr int AIT = (A_ITEMS + NTHR - 1) / NTHR;
     static constexpr int W_ITEMS = WROWS * NPL;
-    static constexpr int WIT = (W_ITEMS + GTHR - 1) / GTHR;
+    static constexpr int WIT = (W_ITEMS + NTHR - 1) / NTHR;
     static constexpr int CPP = BN / 8;  // 16-byte chunks per pixel in the store pass
 };
 
@@ -79,17 +81,13 @@ __device__ __forceinline__ uint4 mul_bf16x8(uint4 a, uint4 b) {
 }
 
 template <int KS, int S, int BN, int CK, int TW, int NW, int DB, int MT>
-__global__ __launch_bounds__(NW * 64, ((DB == 1 || DB == 2) ? NW / 4 : (BN <= 64 ? 2 : 1))) void conv_mfma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(const ConvParams p) {
     using C = Cfg<KS, S, BN, CK, TW, NW, DB, MT>;
-    constexpr int NTHR = C::NTHR, GTHR = C::GTHR;
-    constexpr bool PP = C::PP;
+    constexpr int NTHR = C::NTHR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int grp = PP ? (tid >> 8) : 0;            // ping-pong group (0/1)
-    const int wave = PP ? ((tid >> 6) & 3) : (tid >> 6);  // wave index inside its group: owns pixel rows 2*wave, 2*wave+1
-    const int gtid = PP ? (tid & 255) : tid;
-    unsigned char* sA = smem + (PP ? grp * C::BUF_BYTES : 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // wave w owns pixel rows MT*w .. MT*w + MT - 1
+    unsigned char* sA = smem;
     unsigned char* sW = sA + C::A_BYTES;
     const int r = lane & 31, h = lane >> 5;
 
@@ -116,7 +114,7 @@ __global__ __launch_bounds__(NW * 64, ((DB == 1 || DB == 2) ? NW / 4 : (BN <= 64
     const int iy0 = tile_y * C::TH * S - C::PAD, ix0 = tile_x * TW * S - C::PAD;
 #pragma unroll
     for (int it = 0; it < C::AIT; ++it) {
-        const int i = gtid + GTHR * it;
+        const int i = tid + NTHR * it;
         const int pi = i / C::NPL, c = i - pi * C::NPL;
         const int hy = pi / C::HW, hx = pi - hy * C::HW;
         const int iy = iy0 + hy, ix = ix0 + hx;
@@ -145,9 +143,9 @@ __global__ __launch_bounds__(NW * 64, ((DB == 1 || DB == 2) ? NW / 4 : (BN <= 64
         }                                                                                            \
         const uint4* wsrc = reinterpret_cast<const uint4*>(wbase + (size_t)(chunk_) * C::W_ITEMS * 8); \
         _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
-            const int i = gtid + GTHR * it;                                                          \
+            const int i = tid + NTHR * it;                                                          \
             uint4 t_ = make_uint4(0, 0, 0, 0);                                                       \
-            if ((C::W_ITEMS % GTHR == 0 || i < C::W_ITEMS) && !skipw_) t_ = wsrc[i];                 \
+            if ((C::W_ITEMS % NTHR == 0 || i < C::W_ITEMS) && !skipw_) t_ = wsrc[i];                 \
             w_reg[it] = t_;                                                                          \
         }                                                                                            \
     }
@@ -158,8 +156,8 @@ __global__ __launch_bounds__(NW * 64, ((DB == 1 || DB == 2) ? NW / 4 : (BN <= 64
             if (a_loff[it] >= 0) *reinterpret_cast<uint4*>(sA + (boff_) + a_loff[it]) = a_reg[it];   \
         }                                                                                            \
         _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
-            const int i = gtid + GTHR * it;                                                          \
-            if (C::W_ITEMS % GTHR == 0 || i < C::W_ITEMS) *reinterpret_cast<uint4*>(sW + (boff_) + i * 16) = w_reg[it]; \
+            const int i = tid + NTHR * it;                                                          \
+            if (C::W_ITEMS % NTHR == 0 || i < C::W_ITEMS) *reinterpret_cast<uint4*>(sW + (boff_) + i * 16) = w_reg[it]; \
         }                                                                                            \
     }
 
@@ -241,36 +239,6 @@ __global__ __launch_bounds__(NW * 64, ((DB == 1 || DB == 2) ? NW / 4 : (BN <= 64
             if (chunk + 1 < nchunks) DMA_ISSUE(chunk + 1, C::BUF_BYTES - boff);
             COMPUTE_CHUNK(boff)
         }
-    } else if constexpr (PP) {
-        // Ping-pong: group g owns the chunks c == g (mod 2) and its own LDS buffer.  In half-period k the group k&1 issues the
-        // loads of its next chunk and runs the MFMAs of chunk k, while the other group writes its already-arrived chunk k+1 to
-        // LDS and then parks at the barrier: on every SIMD exactly one of its two waves is in an MFMA phase at any time, so
-        // the matrix pipe never sees two load phases (or two MFMA phases) collide the way two free-running workgroups do.
-        if (grp == 0) { ISSUE_LOADS(0); WRITE_LDS(0); if (nchunks > 2) ISSUE_LOADS(2); }
-        else if (nchunks > 1) ISSUE_LOADS(1);
-        __syncthreads();
-        for (int k = 0; k < nchunks; ++k) {
-            if ((k & 1) == grp) {
-                COMPUTE_CHUNK(0)
-            } else if (k + 1 < nchunks) {
-                WRITE_LDS(0);
-                if (k + 3 < nchunks) ISSUE_LOADS(k + 3);
-            }
-            __syncthreads();
-        }
-    } else if constexpr (DB) {
-        ISSUE_LOADS(0);
-        // double-buffered LDS, ONE barrier per chunk: loads of chunk c+1 fly under the MFMAs of chunk c and are written to
-        // the other buffer afterwards; the barrier both publishes that buffer and retires every read of the current one.
-        WRITE_LDS(0);
-        __syncthreads();
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const int boff = (chunk & 1) * C::BUF_BYTES;
-            if (chunk + 1 < nchunks) ISSUE_LOADS(chunk + 1);
-            COMPUTE_CHUNK(boff)
-            if (chunk + 1 < nchunks) WRITE_LDS(C::BUF_BYTES - boff);
-            __syncthreads();
-        }
     } else {
         ISSUE_LOADS(0);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -297,7 +265,7 @@ __global__ __launch_bounds__(NW * 64, ((DB == 1 || DB == 2) ? NW / 4 : (BN <= 64
         for (int g = 0; g < 4; ++g) bias_r[nt][g] = *reinterpret_cast<const float4*>(bptr + nt * 32 + 8 * g + 4 * h);
     uint2 res_r[MT][C::NT][4];
     const bool has_res = p.res != nullptr;
-    if (has_res && grp == 0) {
+    if (has_res) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int ty = wave * MT + mt, tx = r;
@@ -315,29 +283,13 @@ __global__ __launch_bounds__(NW * 64, ((DB == 1 || DB == 2) ? NW / 4 : (BN <= 64
                 }
         }
     }
-    __syncthreads();
-    unsigned char* stage = smem + C::XCHG_BYTES;
-    if constexpr (PP) {  // sum the two groups' partial accumulators (even chunks + odd chunks) through LDS, lane-linear layout
-        float* xch = reinterpret_cast<float*>(smem) + (size_t)(wave * 64 + lane);
-        if (grp == 1) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) xch[((mt * C::NT + nt) * 16 + j) * 256] = acc[mt][nt][j];
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) acc[mt][nt][j] += xch[((mt * C::NT + nt) * 16 + j) * 256];
-        }
-    }
-    if (grp == 0) {
+    // Register-staged 3x3 layers with plain NHWC output store straight from the accumulators (below): no LDS stage, no barrier,
+    // every wave retires on its own (measured +3..10 % on the short-K stem / stride-2 layers; neutral on the LDS-DMA kernel and
+    // 3x slower for the replicated OUT_UPSAMPLE writes, which keep the staged path).  The other modes stage the bf16 tile in
+    // LDS (it aliases the operand buffers: barrier).
+    const bool direct = KS == 3 && !C::DMA && p.out_mode == OUT_NORMAL && !(p.dbg_skip & 32);
+    if (!direct) __syncthreads();
+    unsigned char* stage = smem;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -362,6 +314,33 @@ __global__ __launch_bounds__(NW * 64, ((DB == 1 || DB == 2) ? NW / 4 : (BN <= 64
     else if (p.act == ACT_SIGMOID) { FOR_ALL_ACC(1.f / (1.f + expf(-v))) }
     else if (p.act == ACT_HSIGMOID) { FOR_ALL_ACC(fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f)) }
 #undef FOR_ALL_ACC
+    if constexpr (KS == 3) {
+        if (direct) {
+            // A lane holds 4 consecutive channels per accumulator quad (8 B as bf16); v_permlane32_swap exchanges quad g of the
+            // upper half-wave with quad g+1 of the lower one, after which every lane owns 8 consecutive channels (16 B) of its
+            // pixel: half-wave h stores channels 16*gp + 8*h .. +7, a pixel's 32 bytes per instruction are contiguous.
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int oy = tile_y * C::TH + wave * MT + mt, ox = tile_x * TW + r;
+                const bool pvalid = oy < p.Ho && ox < p.Wo;
+#pragma unroll
+                for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int g0 = 2 * gp, g1 = 2 * gp + 1;
+                        const uint32_t q0x = pack_bf16x2(acc[mt][nt][4 * g0 + 0], acc[mt][nt][4 * g0 + 1]), q0y = pack_bf16x2(acc[mt][nt][4 * g0 + 2], acc[mt][nt][4 * g0 + 3]);
+                        const uint32_t q1x = pack_bf16x2(acc[mt][nt][4 * g1 + 0], acc[mt][nt][4 * g1 + 1]), q1y = pack_bf16x2(acc[mt][nt][4 * g1 + 2], acc[mt][nt][4 * g1 + 3]);
+                        const auto sx = __builtin_amdgcn_permlane32_swap(q0x, q1x, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(q0y, q1y, false, false);
+                        const uint4 v = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                        const int co = ntile * BN + nt * 32 + 16 * gp + 8 * h;
+                        if (!pvalid || co >= cout_r8) continue;
+                        *reinterpret_cast<uint4*>(p.y + (((size_t)n_img * p.Ho + oy) * p.Wo + ox) * p.y_cstride + p.y_coff + co) = v;
+                    }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int tp = (wave * MT + mt) * TW + r;
@@ -376,10 +355,8 @@ __global__ __launch_bounds__(NW * 64, ((DB == 1 || DB == 2) ? NW / 4 : (BN <= 64
                 *reinterpret_cast<uint2*>(stage + tp * C::STAGE_PITCH + cn * 2) = o;
             }
     }
-    }  // grp == 0
     __syncthreads();
     if (p.out_mode == OUT_CONVT && p.fuse_w != nullptr) {
-        if (grp != 0) return;
         // Fused DBHead tail on the matrix cores: D2[q2][pixel] = W3[q2][c] * act[c][pixel] (K = 64, rows >= 4 of W3 are zero).
         // B fragments come straight from the staged bf16 tile (row pitch 144 B: conflict-free b128 reads), A fragments from the
         // 2 KB pre-packed weight image [kstep][half][32][8]; lanes with h == 0 end up with the 4 outputs of their pixel.
@@ -504,11 +481,8 @@ bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cf
     // on the 128..512-channel stages; 1x1 layers are bandwidth-bound and want 4 workgroups per CU)
     if (cfg->bn == 128) cfg->bn = 64;
     if (ks == 3 && stride == 2 && cfg->bn == 128 && cfg->ck == 32) cfg->bn = 64;  // halo tile is 4x larger: keep LDS < 160 KB
-    // The 8-wave / 16x32-tile / double-buffered-LDS variant (one workgroup per CU, one barrier per chunk) measured SLOWER
-    // than two independent 4-wave workgroups per CU (572 vs 601 TFLOP/s over DBNet): it stays available for experiments.
     if (const char* e = getenv("LUMINA_CONV_CK3")) { if (ks == 3 && stride == 1 && cfg->bn == 64 && cin >= atoi(e)) cfg->ck = 16; }
     if (const char* e = getenv("LUMINA_CONV_NW")) {
-        if (atoi(e) >= 8 && ks == 3 && stride == 1 && cfg->bn == 64 && cfg->ck == 32 && cin >= 64) cfg->nw = atoi(e);
         if ((atoi(e) == 5 || atoi(e) == 6) && ks == 3 && stride == 1 && cfg->bn == 64 && cin >= 64) { cfg->nw = atoi(e); cfg->ck = 16; }
     }
     return true;
@@ -516,8 +490,8 @@ bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cf
 
 const char* conv_kernel_name(const ConvKernelCfg& c) {
     static thread_local char buf[64];
-    const int nw = c.nw >= 8 ? 8 : 4, db = c.nw == 8 ? 1 : (c.nw == 9 ? 2 : (c.nw == 6 ? 3 : 0)), mt = (c.nw == 5 || c.nw == 6) ? 4 : 2;
-    snprintf(buf, sizeof(buf), "conv_mfma_kernel<%d,%d,%d,%d,32,%d,%d,%d>", c.ks, c.stride, c.bn, c.ck, nw, db, mt);  // as rocprofv3 prints it (modulo spaces)
+    const int db = c.nw == 6 ? 3 : 0, mt = (c.nw == 5 || c.nw == 6) ? 4 : 2;
+    snprintf(buf, sizeof(buf), "conv_mfma_kernel<%d,%d,%d,%d,32,4,%d,%d>", c.ks, c.stride, c.bn, c.ck, db, mt);  // as rocprofv3 prints it (modulo spaces)
     return buf;
 }
 
@@ -528,12 +502,8 @@ hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t strea
     static const int dbg = getenv("LUMINA_CONV_DBG") ? atoi(getenv("LUMINA_CONV_DBG")) : 0;
     p.dbg_skip = dbg;
     p.tiles_x = ceil_div(p.Wo, 32);
-    p.tiles_y = ceil_div(p.Ho, cfg.nw * 2);
+    p.tiles_y = ceil_div(p.Ho, 8);
     p.n_tiles = ceil_div(p.Cout, cfg.bn);
-    if (cfg.nw == 8) {  // 512-thread, double-buffered variant (3x3/s1, multi-chunk layers)
-        if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 32) return launch_t<3, 1, 64, 32, 32, 8, 1>(p, stream);
-        return hipErrorInvalidValue;
-    }
     if (cfg.nw == 5) {  // 4 waves, 4 pixel rows per wave: 16x32-pixel tile, 4x2 MFMA register tile, CK = 16
         p.tiles_y = ceil_div(p.Ho, 16);
         if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16) return launch_t<3, 1, 64, 16, 32, 4, 0, 4>(p, stream);
@@ -543,11 +513,6 @@ hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t strea
         p.tiles_y = ceil_div(p.Ho, 16);
         if (p.zeros == nullptr) return hipErrorInvalidValue;
         if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16) return launch_t<3, 1, 64, 16, 32, 4, 3, 4>(p, stream);
-        return hipErrorInvalidValue;
-    }
-    if (cfg.nw == 9) {  // ping-pong variant: 8 waves in two role-alternating groups on one 8x32 tile
-        p.tiles_y = ceil_div(p.Ho, 8);
-        if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 32) return launch_t<3, 1, 64, 32, 32, 8, 2>(p, stream);
         return hipErrorInvalidValue;
     }
     DISPATCH(3, 1, 32, 32) DISPATCH(3, 1, 64, 32) DISPATCH(3, 1, 128, 32) DISPATCH(3, 1, 64, 16)
