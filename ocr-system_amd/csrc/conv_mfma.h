@@ -52,3 +52,8 @@ bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cf
 hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t stream);
 const char* conv_kernel_name(const ConvKernelCfg& cfg);
 
+// Pixel-stationary pointwise kernel (conv_pw.hip) for Cin 64 / 128, all output channels per workgroup; same packed weights
+// (bn 64, ck 32).  Output modes: OUT_NORMAL (optional top-down add) and OUT_CONVT with the fused DBHead tail.
+bool conv_pw_supported(const ConvKernelCfg& cfg, const ConvParams& p);
+hipError_t conv_pw_launch(const ConvParams& p, hipStream_t stream);
+

@@ -243,7 +243,9 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     const bool use_big = !no_big && !flat && L.wpk_big != nullptr && big_blocks >= big_min;
     ConvKernelCfg cfg = L.cfg;
     if (use_big) { cfg = L.cfg_big; p.wpk = L.wpk_big; }
-    hipError_t e = conv_launch(cfg, p, st);
+    static const bool no_pw = getenv("LUMINA_CONV_NO_PW") != nullptr;
+    const bool use_pw = !no_pw && !use_big && conv_pw_supported(cfg, p);
+    hipError_t e = use_pw ? conv_pw_launch(p, st) : conv_launch(cfg, p, st);
     if (e != hipSuccess) return locr_fail(eng, L.name.c_str(), hipGetErrorString(e));
     if (eng->time_convs) {
         HIPCHK(hipEventRecord(e1, st));
@@ -253,7 +255,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         // algorithmic HBM bytes: input once + output once (+ residual) + weights once
         eng->conv_bytes.push_back(2.0 * ((double)x.elems() + px * (out_mode == OUT_CONVT && p.fuse_w ? 4.0 : (double)L.cout) * (out_mode == OUT_UPSAMPLE ? (double)(1 << (2 * up_shift)) : 1.0) + (res ? px * (double)L.cout / (double)(1 << (2 * res_shift)) : 0.0) + (double)L.ks * L.ks * L.cin * L.cout));
         eng->conv_names.push_back(L.name);
-        eng->conv_kernels.push_back(conv_kernel_name(cfg));
+        eng->conv_kernels.push_back(use_pw ? (L.cin == 64 ? "conv_pw_kernel<64>" : "conv_pw_kernel<128>") : conv_kernel_name(cfg));
     }
     return 0;
 }

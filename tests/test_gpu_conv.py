@@ -31,6 +31,9 @@ CASES = [
     (2, 16, 160, 16, 48, 1, 1, 2, False),
     (1, 64, 96, 256, 64, 3, 1, 1, False),
     (1, 7, 200, 64, 8, 1, 1, 4, False),
+    (2, 21, 37, 64, 256, 1, 1, 0, True),     # pixel-stationary pointwise kernel: partial last tile, residual
+    (1, 19, 45, 128, 256, 1, 1, 1, False),
+    (1, 30, 50, 64, 64, 1, 1, 0, False),
 ]
 
 
