@@ -481,7 +481,12 @@ bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cf
     // on the 128..512-channel stages; 1x1 layers are bandwidth-bound and want 4 workgroups per CU)
     if (cfg->bn == 128) cfg->bn = 64;
     if (ks == 3 && stride == 2 && cfg->bn == 128 && cfg->ck == 32) cfg->bn = 64;  // halo tile is 4x larger: keep LDS < 160 KB
-    if (const char* e = getenv("LUMINA_CONV_CK3")) { if (ks == 3 && stride == 1 && cfg->bn == 64 && cin >= atoi(e)) cfg->ck = 16; }
+    // stride-2 layers: the halo tile is 4x larger per output pixel; 16-channel chunks keep LDS <= ~55 KB so that two to three
+    // workgroups share a CU (measured 3x3/s2: 0.305 -> 0.234 ms, 0.242 -> 0.186 ms per 16 pages)
+    if (stride == 2) cfg->ck = 16;
+    if (const char* e = getenv("LUMINA_CONV_CKS2")) { if (stride == 2) cfg->ck = atoi(e) == 32 && cin % 32 == 0 ? 32 : 16; }
+    if (ks == 3 && stride == 1 && cin == 32 && cfg->bn == 32) cfg->ck = 16;  // stem.conv2: two pipelined chunks, +4 %
+    if (const char* e = getenv("LUMINA_CONV_CK3")) { if (ks == 3 && stride == 1 && cin >= atoi(e)) cfg->ck = 16; }
     if (const char* e = getenv("LUMINA_CONV_NW")) {
         if ((atoi(e) == 5 || atoi(e) == 6) && ks == 3 && stride == 1 && cfg->bn == 64 && cin >= 64) { cfg->nw = atoi(e); cfg->ck = 16; }
     }
@@ -516,9 +521,10 @@ hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t strea
         return hipErrorInvalidValue;
     }
     DISPATCH(3, 1, 32, 32) DISPATCH(3, 1, 64, 32) DISPATCH(3, 1, 128, 32) DISPATCH(3, 1, 64, 16)
-    DISPATCH(3, 2, 32, 32) DISPATCH(3, 2, 64, 32)
+    DISPATCH(3, 2, 32, 32) DISPATCH(3, 2, 64, 32) DISPATCH(3, 2, 64, 16)
     DISPATCH(1, 1, 32, 32) DISPATCH(1, 1, 64, 32) DISPATCH(1, 1, 128, 32)
     DISPATCH(1, 1, 32, 16) DISPATCH(1, 1, 64, 16) DISPATCH(1, 1, 128, 16)
-    DISPATCH(2, 2, 32, 32) DISPATCH(2, 2, 64, 32) DISPATCH(2, 2, 128, 32)
+    DISPATCH(2, 2, 32, 32) DISPATCH(2, 2, 64, 32) DISPATCH(2, 2, 128, 32) DISPATCH(2, 2, 32, 16) DISPATCH(2, 2, 64, 16)
+    DISPATCH(3, 2, 32, 16) DISPATCH(3, 1, 32, 16)
     return hipErrorInvalidValue;
 }
