@@ -97,10 +97,17 @@ def main():
     pipe = OcrPipeline(eng, post=arch.TEXT_PATH_POST)
     pages = make_pages(torch, args.pages, 2024 + 1000 * rank, device)
 
-    def step():
-        dets, _ = pipe.run(pages)
-        if distributed:
-            dets = all_gather_pages(dets, pipe.charset, device=device, pages_per_rank=args.pages)
+    side = torch.cuda.Stream(device) if distributed else None   # result gather runs beside the next step's detection kernels
+
+    def gather(dets):
+        return all_gather_pages(dets, pipe.charset, device=device, pages_per_rank=args.pages, stream=side) if distributed else dets
+
+    def run_steps(k):
+        """k steps through OcrPipeline.run_many: step i's host-side string decode (and result gather) overlaps the device
+        work of step i+1; every step's work, including the last decode, is finished when this returns."""
+        dets = None
+        for d, _ in pipe.run_many(pages for _ in range(k)):
+            dets = gather(d)
         return dets
 
     def fence():
@@ -109,12 +116,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        dets = step()
+    dets = run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        dets = step()
+    dets = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:

@@ -81,10 +81,16 @@ def unpack_pages(buf: np.ndarray, charset: Sequence[str]):
     return GatheredPages(buf, charset).pages()
 
 
-def all_gather_pages(local_pages: Sequence, charset: Sequence[str], device=None, pages_per_rank: int = 0):
+def all_gather_pages(local_pages: Sequence, charset: Sequence[str], device=None, pages_per_rank: int = 0, stream=None):
     """Gather every rank's per-page results; returns a GatheredPages over ALL pages in global page order.
     Requires torch.distributed to be initialised; every rank must call it with the same pages_per_rank
-    (ranks holding fewer pages are padded with empty pages)."""
+    (ranks holding fewer pages are padded with empty pages).  `stream`: a side torch.cuda.Stream to run the two small
+    collectives and their copies on, so that they neither wait for nor delay compute already queued on the current stream
+    (the inputs are host data: there is nothing to wait for)."""
+    if stream is not None:
+        import torch
+        with torch.cuda.stream(stream):
+            return all_gather_pages(local_pages, charset, device=device, pages_per_rank=pages_per_rank)
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()

@@ -32,6 +32,19 @@ class PageDetections:
         return [(self.quads[i].tolist(), self.texts[i], float(self.scores[i])) for i in range(len(self.texts))]
 
 
+@dataclass
+class _Pending:
+    """A batch whose device work is enqueued: pinned host copies of the outputs + the event that completes them."""
+    b: int
+    w: int
+    h: int
+    counts_h: np.ndarray
+    n: int
+    processed: object
+    host: Optional[list] = None
+    event: Optional[object] = None
+
+
 class OcrPipeline:
     def __init__(self, engine: Engine, charset: Optional[List[str]] = None, max_dimension: int = 2000, post: Optional[dict] = None):
         self.eng = engine
@@ -54,12 +67,23 @@ class OcrPipeline:
         return self.eng.det_postprocess(prob, h, w, **self.post)
 
     def recognize(self, processed, boxes, scores, counts) -> List[PageDetections]:
+        return self.finish(self.submit_recognize(processed, boxes, scores, counts))[0]
+
+    # ---- split submission: lets the host-side decode of batch k overlap the device work of batch k+1 ----------------
+    def submit_detect(self, pages, enhance: bool = True):
+        """Enqueue resize/enhance + DBNet + DB post-process; no host synchronisation. -> handle for submit_recognize."""
+        processed = self.preprocess(pages, enhance)
+        return (processed,) + tuple(self.detect(processed))
+
+    def submit_recognize(self, processed, boxes, scores, counts) -> "_Pending":
+        """One host sync (box counts), then crop + CRNN + CTC and the device->pinned-host copies are enqueued. -> pending."""
         import torch
         b, h, w, _ = processed.shape
         counts_h = counts.cpu().numpy()  # the one host sync of the pipeline
         n = int(counts_h.sum())
+        pend = _Pending(b=b, w=w, h=h, counts_h=counts_h, n=n, processed=processed)
         if n == 0:
-            return [PageDetections(np.zeros((0, 8), np.int32), [], np.zeros(0, np.float32), np.zeros(0, np.float32), w, h) for _ in range(b)]
+            return pend
         mask = torch.arange(boxes.shape[1], device=boxes.device)[None, :] < counts[:, None]
         quads = boxes[mask].contiguous()
         page_idx = torch.arange(b, device=boxes.device, dtype=torch.int32)[:, None].expand(b, boxes.shape[1])[mask].contiguous()
@@ -67,20 +91,40 @@ class OcrPipeline:
         crops, widths = self.eng.rec_crop(processed, quads, page_idx)
         idx, prob = self.eng.rec_forward(crops, widths)
         text, length, score = self.eng.ctc_decode(idx, prob)
-        text_h, len_h, score_h = text.cpu().numpy(), length.cpu().numpy(), score.cpu().numpy()
-        quads_h, det_h = quads.cpu().numpy(), det_sc.cpu().numpy()
+        pend.host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True) for t in (text, length, score, quads, det_sc)]
+        pend.event = torch.cuda.Event()
+        pend.event.record(torch.cuda.current_stream(processed.device))
+        return pend
+
+    def finish(self, pend: "_Pending") -> Tuple[List[PageDetections], "object"]:
+        """Wait for the pending batch's copies and build the per-page results (string decode on the host)."""
+        b, w, h = pend.b, pend.w, pend.h
+        if pend.n == 0:
+            return [PageDetections(np.zeros((0, 8), np.int32), [], np.zeros(0, np.float32), np.zeros(0, np.float32), w, h) for _ in range(b)], pend.processed
+        pend.event.synchronize()
+        text_h, len_h, score_h, quads_h, det_h = (t.numpy() for t in pend.host)
         cps = self._codepoints[np.maximum(text_h, 0)]          # [n, 80] uint32 code points; one utf-32 decode per line
         out, off = [], 0
         for p in range(b):
-            c = int(counts_h[p])
+            c = int(pend.counts_h[p])
             texts = [cps[i, : len_h[i]].tobytes().decode("utf-32-le") for i in range(off, off + c)]
             out.append(PageDetections(quads_h[off:off + c], texts, score_h[off:off + c], det_h[off:off + c], w, h,
                                       text_h[off:off + c], len_h[off:off + c]))
             off += c
-        return out
+        return out, pend.processed
+
+    def run_many(self, batches, enhance: bool = True):
+        """Generator over batches: yields (detections, processed) per batch, in order, with batch k's host decode running
+        while the device works on batch k+1's detection half."""
+        pending = None
+        for pages in batches:
+            h = self.submit_detect(pages, enhance)
+            if pending is not None:
+                yield self.finish(pending)
+            pending = self.submit_recognize(*h)
+        if pending is not None:
+            yield self.finish(pending)
 
     def run(self, pages, enhance: bool = True) -> Tuple[List[PageDetections], "object"]:
         """-> (per-page detections, processed pages on device)."""
-        processed = self.preprocess(pages, enhance)
-        boxes, scores, counts = self.detect(processed)
-        return self.recognize(processed, boxes, scores, counts), processed
+        return self.finish(self.submit_recognize(*self.submit_detect(pages, enhance)))

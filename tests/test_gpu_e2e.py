@@ -94,3 +94,20 @@ def test_provider_end_to_end_schema(engine, tmp_path):
     two = s.process_pages_sync([Image.fromarray(page), Image.fromarray(page)])
     assert all(o.success for o in two) and two[0].layout_boxes == pg.layout_boxes and two[1].page_number == 2
     assert s.get_status()["client_initialized"] and s.is_model_loaded
+
+
+def test_run_many_equals_run(engine, det_weights, rec_weights):
+    """The split submission (host decode of batch k overlapping the device work of batch k+1) returns what run() returns."""
+    engine.load_det(det_weights)
+    engine.load_rec(rec_weights)
+    pipe = OcrPipeline(engine, max_dimension=800, post=arch.TEXT_PATH_POST)
+    batches = [torch.from_numpy(np.stack([synth.synth_page(560, 800, 70 + 2 * k + i, n_lines=10)[0] for i in range(2)])).cuda() for k in range(3)]
+    batches.append(torch.from_numpy(np.full((1, 560, 800, 3), 255, np.uint8)).cuda())   # a blank page: zero boxes
+    single = [pipe.run(b)[0] for b in batches]
+    many = [d for d, _ in pipe.run_many(iter(batches))]
+    assert len(many) == len(single)
+    for ds, dm in zip(single, many):
+        assert len(ds) == len(dm)
+        for a, b in zip(ds, dm):
+            assert np.array_equal(a.quads, b.quads) and a.texts == b.texts and np.array_equal(a.scores, b.scores)
+    assert sum(len(p.texts) for p in single[0]) > 0 and len(single[-1][0].texts) == 0
