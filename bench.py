@@ -172,7 +172,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": "mean HBM bytes/launch of this kernel in a 16-page det forward (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm.json); bench launches cover 16-page sub-batches too",
-                         "family": {"kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": len(rows),
+                         "family": {"kernel": "all conv launches (conv_mfma_kernel instantiations + conv_pw_kernel)", "launches_per_step": len(rows),
                                     "ms_per_step": round(fam_ms, 3), "achieved": round(fam_gf / fam_ms, 2),
                                     "frac": round(fam_gf / fam_ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}},
         }
