@@ -54,6 +54,7 @@ int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value) {
     else if (!strcmp(key, "keep_taps")) h->keep_taps = value != 0;
     else if (!strcmp(key, "time_convs")) h->time_convs = value != 0;
     else if (!strcmp(key, "fuse_head")) h->fuse_head = value != 0;
+    else if (!strcmp(key, "fuse_mb")) h->fuse_mb = value != 0;
     else return locr_fail(h, "set_option: unknown key", key);
     return 0;
 }

@@ -7,6 +7,7 @@
 
 #include "common.h"
 #include "conv_mfma.h"
+#include "mbconv.h"
 
 struct Tensor4 {
     bf16_t* p = nullptr;
@@ -37,6 +38,7 @@ struct RecBlock {
     bool se, res;
     ConvLayer expand, project;
     DwLayer dw;
+    bf16_t* we_pk = nullptr; float* be_pk = nullptr;  // expand weights / bias in the fused expand+depthwise kernel's layout (mbconv.h)
     SeLayer sel;
 };
 
@@ -65,6 +67,7 @@ struct lumina_ocr {
     std::map<std::string, Tensor4> taps;  // last forward's intermediates (debug / parity tests)
     bool keep_taps = false;
     bool fuse_head = true;  // head.convt3 fused into head.convt2's epilogue
+    bool fuse_mb = true;    // recogniser blocks: expand + depthwise in one kernel (the expanded tensor stays in LDS)
     // per-kernel event timing (bench roofline): accumulated conv-kernel time of the last det forward
     bool time_convs = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_events;

@@ -438,6 +438,20 @@ int eng_load_rec(lumina_ocr* eng, const void* blob, size_t n) {
         const std::string p = "rec.b" + std::to_string(i);
         if (!make_conv(eng, m, p + ".expand", 1, 1, B.cin, B.exp, cp16(B.cin), cp16(B.exp), B.act, &B.expand)) return 1;
         if (!make_dw(eng, m, p + ".dw", B.k, B.exp, cp16(B.exp), &B.dw)) return locr_fail(eng, "dw", p.c_str());
+        {   // the same expand weights once more, in the fused kernel's fragment order
+            const HostBlobTensor *w, *b;
+            if (!get_wb(eng, m, p + ".expand", &w, &b)) return 1;
+            const int ec = cp16(B.exp), cc = cp16(B.cin);
+            std::vector<bf16_t> padded((size_t)ec * cc, 0), packed(mbconv_expand_packed_elems(ec, cc));
+            const bf16_t* src = reinterpret_cast<const bf16_t*>(w->data);
+            for (int r = 0; r < B.exp; ++r) memcpy(&padded[(size_t)r * cc], &src[(size_t)r * B.cin], sizeof(bf16_t) * B.cin);
+            mbconv_pack_expand(padded.data(), ec, cc, packed.data());
+            std::vector<float> bias((size_t)((ec + 31) / 32) * 32, 0.f);
+            memcpy(bias.data(), b->data, sizeof(float) * B.exp);
+            B.we_pk = static_cast<bf16_t*>(dev_upload(eng, packed.data(), packed.size() * sizeof(bf16_t)));
+            B.be_pk = static_cast<float*>(dev_upload(eng, bias.data(), bias.size() * sizeof(float)));
+            if (!B.we_pk || !B.be_pk) return locr_fail(eng, "upload", (p + ".expand (fused)").c_str());
+        }
         if (B.se && !make_se(eng, m, p, B.exp, cp16(B.exp), B.se_mid, &B.sel)) return 1;
         if (!make_conv(eng, m, p + ".project", 1, 1, B.exp, B.cout, cp16(B.exp), cp16(B.cout), ACT_NONE, &B.project)) return 1;
         cin = B.cout;
@@ -506,11 +520,21 @@ static int rec_forward_sub(lumina_ocr* eng, const uint8_t* crops, const int* wid
     tap(eng, "rec.conv1", x);
     for (size_t bi = 0; bi < eng->rblocks.size(); ++bi) {
         RecBlock& B = eng->rblocks[bi];
-        Tensor4 e1 = ws_tensor(eng, N, x.h, x.w, cp16(B.exp));
-        RUN(eng_run_conv(eng, B.expand, x, &e1, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
         const int ho = (x.h + 2 * (B.k / 2) - B.k) / B.stride_h + 1;
+        MbParams mp{};
+        mp.we = B.we_pk; mp.be = B.be_pk; mp.wd = B.dw.w; mp.bd = B.dw.bias;
+        mp.N = N; mp.H = x.h; mp.W = x.w; mp.cin = x.c; mp.expc = cp16(B.exp); mp.Ho = ho; mp.act = B.act;
+        const bool fused_mb = eng->fuse_mb && mbconv_supported(mp, B.k, B.stride_h);
+        Tensor4 e1{};
+        if (!fused_mb || dry) e1 = ws_tensor(eng, N, x.h, x.w, cp16(B.exp));   // (dry run sizes the arena for the unfused path too)
         Tensor4 d = ws_tensor(eng, N, ho, x.w, cp16(B.exp));
-        LAUNCH("dwconv", dwconv_launch(e1.p, B.dw.w, B.dw.bias, d.p, N, e1.h, e1.w, e1.c, B.k, B.stride_h, B.act, st));
+        if (fused_mb) {
+            mp.x = x.p; mp.d = d.p;
+            if (!dry && x.p && d.p) LAUNCH("mbconv", mbconv_launch(mp, B.k, B.stride_h, st));
+        } else {
+            RUN(eng_run_conv(eng, B.expand, x, &e1, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
+            LAUNCH("dwconv", dwconv_launch(e1.p, B.dw.w, B.dw.bias, d.p, N, e1.h, e1.w, e1.c, B.k, B.stride_h, B.act, st));
+        }
         const bf16_t* se_gate_ptr = nullptr;
         if (B.se) {
             bf16_t* gate = static_cast<bf16_t*>(eng_ws_alloc(eng, (size_t)N * d.c * sizeof(bf16_t)));

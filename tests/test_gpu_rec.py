@@ -56,6 +56,26 @@ def test_rec_forward_taps(engine, rec_weights):
     assert rel < 0.1, rel
 
 
+def test_fused_expand_depthwise_is_bit_identical(engine, rec_weights):
+    """The fused expand+depthwise kernel (expanded tensor in LDS) and the unfused conv + depthwise pair compute the same
+    arithmetic in the same order: every block output and the final argmax / max-prob must match bit for bit."""
+    crops = _crops(9, 99)
+    widths = np.array([320, 320, 200, 77, 320, 131, 33, 320, 250], np.int32)
+    engine.load_rec(rec_weights)
+    engine.set_option("keep_taps", 1)
+    outs = []
+    for fuse in (1, 0):
+        engine.set_option("fuse_mb", fuse)
+        idx, prob = engine.rec_forward(torch.from_numpy(crops).cuda(), torch.from_numpy(widths).cuda())
+        torch.cuda.synchronize()
+        outs.append(([engine.read_tap("rec.b%d" % i).copy() for i in range(11)], idx.cpu().numpy(), prob.cpu().numpy()))
+    engine.set_option("fuse_mb", 1)
+    engine.set_option("keep_taps", 0)
+    for i, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        assert np.array_equal(a, b), "rec.b%d" % i
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
 def test_ctc_fc_argmax_exact_on_same_sequence(engine, rec_weights):
     """The fused FC+argmax+softmax kernel vs numpy on the engine's own bf16 LSTM output (same inputs)."""
     crops = _crops(5, 99)
