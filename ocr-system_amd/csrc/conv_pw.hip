@@ -8,8 +8,9 @@
 //     the packed weight image in L1/L2 into registers — the whole layer's weights are 8-64 KB and shared by every workgroup —
 //     and the next group's fragments are requested before the current group's epilogue: no barrier inside the loop, the four
 //     waves run independently (wave w owns pixels 64w .. 64w+63 = two 32-pixel MFMA column tiles);
-//   * epilogue per group, in registers: bias, nearest-upsampled top-down add (FPN), activation; then either
-//     v_permlane32_swap + 16-byte NHWC stores, or (DBHead) the fused transposed-conv tail: the activated 64-channel tile is
+//   * epilogue per group, in registers: bias, nearest-upsampled top-down add (FPN), activation; then NHWC stores through a
+//     wave-local LDS stage (full 128-byte lines per pixel; Cin = 128: v_permlane32_swap + 16-byte stores), or (DBHead) the
+//     fused transposed-conv tail: the activated 64-channel tile is
 //     staged wave-locally in LDS, contracted with the 64->4 weights on the matrix cores, sigmoid, 2x2 probability block.
 // Same arithmetic (fp32 MFMA accumulation over k in the same order, one bf16 rounding per stored tensor), same packed
 // weights (bn 64, ck 32) and the same ConvParams as conv_mfma.hip, which remains the general 1x1 path.
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvParams p, con
     constexpr int NS = CIN / 8, KSTEPS = CIN / 16, A_BYTES = PW_PX * CIN * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;
-    unsigned char* stage = smem + A_BYTES;  // only allocated for the fused DBHead tail
+    unsigned char* stage = smem + A_BYTES;  // wave-local rows: output staging / the fused DBHead tail's operand
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const long long pix0 = (long long)blockIdx.x * PW_PX;
 
@@ -153,22 +154,50 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvParams p, con
         }
 
         if constexpr (!fused) {
-            // a lane's quads of 4 channels -> 8 consecutive channels per lane (see conv_mfma.hip's direct epilogue)
+            if constexpr (CIN != 64) {
+                // direct stores: v_permlane32_swap gives every lane 8 consecutive channels, 32 bytes per pixel per instruction
+                // (Cin = 128: the 64 KB pixel tile leaves no LDS for a stage at two workgroups per CU)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) {
-                        const int g0 = 2 * gp, g1 = 2 * gp + 1;
-                        const uint32_t q0x = pack_bf16x2(acc[mt][nt][4 * g0 + 0], acc[mt][nt][4 * g0 + 1]), q0y = pack_bf16x2(acc[mt][nt][4 * g0 + 2], acc[mt][nt][4 * g0 + 3]);
-                        const uint32_t q1x = pack_bf16x2(acc[mt][nt][4 * g1 + 0], acc[mt][nt][4 * g1 + 1]), q1y = pack_bf16x2(acc[mt][nt][4 * g1 + 2], acc[mt][nt][4 * g1 + 3]);
-                        const auto sx = __builtin_amdgcn_permlane32_swap(q0x, q1x, false, false);
-                        const auto sy = __builtin_amdgcn_permlane32_swap(q0y, q1y, false, false);
-                        const int co = q * 64 + nt * 32 + 16 * gp + 8 * h;
-                        if (pvalid[mt] && co < cout_r8)
-                            *reinterpret_cast<uint4*>(p.y + (size_t)gpix[mt] * p.y_cstride + p.y_coff + co) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-                    }
+                        for (int gp = 0; gp < 2; ++gp) {
+                            const int g0 = 2 * gp, g1 = 2 * gp + 1;
+                            const uint32_t q0x = pack_bf16x2(acc[mt][nt][4 * g0 + 0], acc[mt][nt][4 * g0 + 1]), q0y = pack_bf16x2(acc[mt][nt][4 * g0 + 2], acc[mt][nt][4 * g0 + 3]);
+                            const uint32_t q1x = pack_bf16x2(acc[mt][nt][4 * g1 + 0], acc[mt][nt][4 * g1 + 1]), q1y = pack_bf16x2(acc[mt][nt][4 * g1 + 2], acc[mt][nt][4 * g1 + 3]);
+                            const auto sx = __builtin_amdgcn_permlane32_swap(q0x, q1x, false, false);
+                            const auto sy = __builtin_amdgcn_permlane32_swap(q0y, q1y, false, false);
+                            const int co = q * 64 + nt * 32 + 16 * gp + 8 * h;
+                            if (pvalid[mt] && co < cout_r8)
+                                *reinterpret_cast<uint4*>(p.y + (size_t)gpix[mt] * p.y_cstride + p.y_coff + co) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                        }
+            } else {
+                // wave-local LDS stage -> every store instruction writes 8 pixels x 128 contiguous bytes: full lines instead of four
+                // 32-byte pieces per line (measured on fpn.in2, 1.5 GB written per 16 pages: 0.68 -> 0.55 ms)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int tp = wave * 64 + mt * 32 + r;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            uint2 o;
+                            o.x = pack_bf16x2(acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1]);
+                            o.y = pack_bf16x2(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
+                            *reinterpret_cast<uint2*>(stage + tp * PW_STAGE_PITCH + (nt * 32 + 8 * g + 4 * h) * 2) = o;
+                        }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = lane + 64 * k;           // 64 pixels x 8 chunks of this wave
+                    const int sp = wave * 64 + (i >> 3), ch = i & 7;
+                    const long long gp = pix0 + sp;
+                    const int co = q * 64 + ch * 8;
+                    const uint4 v = *reinterpret_cast<const uint4*>(stage + sp * PW_STAGE_PITCH + ch * 16);
+                    if (gp < total_px && co < cout_r8) *reinterpret_cast<uint4*>(p.y + (size_t)gp * p.y_cstride + p.y_coff + co) = v;
+                }
+            }
         } else {
             // fused DBHead tail: group q is sub-pixel q of the first transposed conv (convt_c == 64).  The wave stages its own 64
             // activated pixels x 64 channels and contracts them with the 64 -> 4 weights of the second transposed conv.
@@ -212,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvParams p, con
 template <int CIN, int MODE>
 hipError_t launch_pw(const ConvParams& p, long long total_px, hipStream_t stream) {
     auto kern = conv_pw_kernel<CIN, MODE>;
-    const size_t lds = (size_t)PW_PX * CIN * 2 + (p.out_mode == OUT_CONVT ? (size_t)PW_PX * PW_STAGE_PITCH : 0);
+    const size_t lds = (size_t)PW_PX * CIN * 2 + (CIN == 64 ? (size_t)PW_PX * PW_STAGE_PITCH : 0);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PW_PX * CIN * 2 + PW_PX * PW_STAGE_PITCH);
