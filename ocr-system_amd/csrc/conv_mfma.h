@@ -7,6 +7,7 @@ enum ConvOutMode : int {
     OUT_UPSAMPLE = 1,  // nearest-neighbour replicate each output pixel f x f times (f = 1 << up_shift)
     OUT_CONVT = 2,     // 2x2/s2 transposed conv: gemm column q*C + co -> y[n, 2oy+dy, 2ox+dx, co], q = dy*2+dx
     OUT_CONVT1 = 3,    // same with C == 1 (probability map): gemm columns 0..3 -> 2x2 block of a 1-channel map
+    OUT_POOL = 4,      // 3x3 / stride-2 / pad-1 max pool of the conv output, fused: y[n, (Ho-1)/2+1, (Wo-1)/2+1, co] (LDS-DMA 16x32-tile kernel only)
 };
 
 struct ConvParams {

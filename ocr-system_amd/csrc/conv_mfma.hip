@@ -111,7 +111,12 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
     const int cadv = blk_dbg ? p.H * p.W * 16 : CK;
     int a_goff[C::AIT], a_loff[C::AIT];
     int a_gate[KS == 1 ? C::AIT : 1];   // fused SE gate (1x1 layers): offset of this item's 8 gate values, -1 = none
-    const int iy0 = tile_y * C::TH * S - C::PAD, ix0 = tile_x * TW * S - C::PAD;
+    // output-tile origin.  OUT_POOL: a tile yields (TH-2)/2 x (TW-2)/2 pooled pixels and needs the conv rows / columns
+    // 2*py - 1 .. 2*py + 1 of each: tiles step by TH-2 / TW-2 conv pixels and start one row / column early (overlap = the
+    // price of never writing the un-pooled tensor: 14/16 x 30/32 = 82 % of the MFMA work is net)
+    const bool pool = C::DMA && p.out_mode == OUT_POOL;
+    const int oyb = pool ? tile_y * (C::TH - 2) - 1 : tile_y * C::TH, oxb = pool ? tile_x * (TW - 2) - 1 : tile_x * TW;
+    const int iy0 = oyb * S - C::PAD, ix0 = oxb * S - C::PAD;
 #pragma unroll
     for (int it = 0; it < C::AIT; ++it) {
         const int i = tid + NTHR * it;
@@ -269,8 +274,8 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int ty = wave * MT + mt, tx = r;
-            const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
-            const bool pvalid = oy < p.Ho && ox < p.Wo && (p.pix_limit == 0 || oy * p.Wo + ox < p.pix_limit);
+            const int oy = oyb + ty, ox = oxb + tx;
+            const bool pvalid = oy >= 0 && ox >= 0 && oy < p.Ho && ox < p.Wo && (p.pix_limit == 0 || oy * p.Wo + ox < p.pix_limit);
             const bf16_t* rrow = p.res + (((size_t)n_img * p.res_h + (oy >> p.res_shift)) * p.res_w + (ox >> p.res_shift)) * p.res_cstride + ntile * BN;
 #pragma unroll
             for (int nt = 0; nt < C::NT; ++nt)
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
             // pixel: half-wave h stores channels 16*gp + 8*h .. +7, a pixel's 32 bytes per instruction are contiguous.
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int oy = tile_y * C::TH + wave * MT + mt, ox = tile_x * TW + r;
+                const int oy = oyb + wave * MT + mt, ox = oxb + r;
                 const bool pvalid = oy < p.Ho && ox < p.Wo;
 #pragma unroll
                 for (int nt = 0; nt < C::NT; ++nt)
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
                     d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, d2, 0, 0, 0);
                 }
                 const int ty = wave * MT + mt, tx = r;
-                const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
+                const int oy = oyb + ty, ox = oxb + tx;
                 if (h == 0 && oy < p.Ho && ox < p.Wo) {
                     const int yy = 4 * oy + 2 * (q >> 1), xx = 4 * ox + 2 * (q & 1);
                     bf16_t* dst = p.y + ((size_t)n_img * (4 * p.Ho) + yy) * (size_t)(4 * p.Wo) + xx;
@@ -386,13 +391,49 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
         }
         return;
     }
+    if constexpr (C::DMA) {
+        if (pool) {
+            // fused 3x3 / s2 / p1 max pool over the staged bf16 tile: pooled pixel (pr, pc) of this tile = max over tile rows
+            // 2pr .. 2pr+2, columns 2pc .. 2pc+2 that lie inside the conv output (pool padding is -inf: skipped)
+            constexpr int PH = (C::TH - 2) / 2, PW = (TW - 2) / 2;
+            const int Hq = (p.Ho - 1) / 2 + 1, Wq = (p.Wo - 1) / 2 + 1;
+            for (int i = tid; i < PH * PW * C::CPP; i += NTHR) {
+                const int pp = i / C::CPP, ch = i - pp * C::CPP;
+                const int pr = pp / PW, pc = pp - pr * PW;
+                const int py = tile_y * PH + pr, px = tile_x * PW + pc;
+                const int co = ntile * BN + ch * 8;
+                if (py >= Hq || px >= Wq || co >= cout_r8) continue;
+                float m[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = -3.0e38f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int lr = 2 * pr + dy, lc = 2 * pc + dx;
+                        const int cy = oyb + lr, cx = oxb + lc;
+                        if (cy < 0 || cy >= p.Ho || cx < 0 || cx >= p.Wo) continue;
+                        const uint4 v = *reinterpret_cast<const uint4*>(stage + (lr * TW + lc) * C::STAGE_PITCH + ch * 16);
+                        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            m[2 * j] = fmaxf(m[2 * j], __uint_as_float(w4[j] << 16));
+                            m[2 * j + 1] = fmaxf(m[2 * j + 1], __uint_as_float(w4[j] & 0xFFFF0000u));
+                        }
+                    }
+                const uint4 o = make_uint4(pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7]));
+                *reinterpret_cast<uint4*>(p.y + (((size_t)n_img * Hq + py) * Wq + px) * p.y_cstride + p.y_coff + co) = o;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < (C::TH * TW * C::CPP + NTHR - 1) / NTHR; ++k) {
         const int i = tid + NTHR * k;
         const int tp = i / C::CPP, ch = i - tp * C::CPP;
         if (tp >= C::TH * TW) continue;
         const int ty = tp / TW, tx = tp - ty * TW;
-        const int oy = tile_y * C::TH + ty, ox = tile_x * TW + tx;
+        const int oy = oyb + ty, ox = oxb + tx;
         const int co = ntile * BN + ch * 8;
         if (oy >= p.Ho || ox >= p.Wo || co >= cout_r8 || (p.pix_limit != 0 && oy * p.Wo + ox >= p.pix_limit)) continue;
         const uint4 v = *reinterpret_cast<const uint4*>(stage + tp * C::STAGE_PITCH + ch * 16);
@@ -514,8 +555,13 @@ hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t strea
         if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16) return launch_t<3, 1, 64, 16, 32, 4, 0, 4>(p, stream);
         return hipErrorInvalidValue;
     }
+    if (p.out_mode == OUT_POOL && cfg.nw != 6) return hipErrorInvalidValue;
     if (cfg.nw == 6) {  // same tile as nw == 5, operands by LDS-DMA into a 2-deep ring (row-major weight packing)
         p.tiles_y = ceil_div(p.Ho, 16);
+        if (p.out_mode == OUT_POOL) {  // tiles step over the POOLED grid: 7 x 15 pooled pixels per tile
+            p.tiles_y = ceil_div((p.Ho - 1) / 2 + 1, 7);
+            p.tiles_x = ceil_div((p.Wo - 1) / 2 + 1, 15);
+        }
         if (p.zeros == nullptr) return hipErrorInvalidValue;
         if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16) return launch_t<3, 1, 64, 16, 32, 4, 3, 4>(p, stream);
         return hipErrorInvalidValue;

@@ -67,6 +67,7 @@ struct lumina_ocr {
     std::map<std::string, Tensor4> taps;  // last forward's intermediates (debug / parity tests)
     bool keep_taps = false;
     bool fuse_head = true;  // head.convt3 fused into head.convt2's epilogue
+    bool fuse_pool = true;  // stem.conv3's epilogue does the 3x3/s2 max pool
     bool fuse_mb = true;    // recogniser blocks: expand + depthwise in one kernel (the expanded tensor stays in LDS)
     // per-kernel event timing (bench roofline): accumulated conv-kernel time of the last det forward
     bool time_convs = false;

@@ -115,7 +115,7 @@ static bool make_conv(lumina_ocr* eng, const std::map<std::string, HostBlobTenso
     // 16x32-tile kernel: operands by LDS-DMA into a 2-deep ring (nw == 6, default: +3..5 % on the 128..256-channel layers) or
     // through registers (nw == 5, LUMINA_CONV_DMA=0)
     static const int dma = getenv("LUMINA_CONV_DMA") != nullptr ? atoi(getenv("LUMINA_CONV_DMA")) : 1;
-    if (ks == 3 && stride == 1 && L->cfg.bn == 64 && cin_p >= 64 && L->cfg.nw == 4) {
+    if (ks == 3 && stride == 1 && L->cfg.bn == 64 && (cin_p >= 64 || name == "stem.conv3") && L->cfg.nw == 4) {  // stem.conv3: for the fused max pool
         L->cfg_big = L->cfg; L->cfg_big.nw = dma ? 6 : 5; L->cfg_big.ck = 16;
         std::vector<bf16_t> packed2(conv_packed_weight_elems(cout_p, ks, cin_p, 64));
         pack_conv_weights(padded.data(), cout_p, ks, cin_p, 64, 16, packed2.data(), dma ? 1 : 0);
@@ -240,7 +240,8 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     // 16x32 tiles (less LDS and L2 traffic per MFMA) once they still give >= 2 workgroups per CU on all 256 CUs twice over
     const long long big_blocks = (long long)p.N * ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32) * ((L.cout + L.cfg.bn - 1) / L.cfg.bn);
     static const long long big_min = getenv("LUMINA_CONV_BIG_MIN") ? atoll(getenv("LUMINA_CONV_BIG_MIN")) : 1024;
-    const bool use_big = !no_big && !flat && L.wpk_big != nullptr && big_blocks >= big_min;
+    if (out_mode == OUT_POOL && (L.wpk_big == nullptr || L.cfg_big.nw != 6)) return locr_fail(eng, "fused max pool needs the LDS-DMA conv kernel", L.name.c_str());
+    const bool use_big = out_mode == OUT_POOL || (!no_big && !flat && L.wpk_big != nullptr && big_blocks >= big_min && L.cin >= 64);
     ConvKernelCfg cfg = L.cfg;
     if (use_big) { cfg = L.cfg_big; p.wpk = L.wpk_big; }
     static const bool no_pw = getenv("LUMINA_CONV_NO_PW") != nullptr;
@@ -253,7 +254,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         const double px = flat ? (double)p.pix_limit : (double)p.N * p.Ho * p.Wo;
         eng->conv_flops.push_back(2.0 * px * L.ks * L.ks * L.cin * L.cout);
         // algorithmic HBM bytes: input once + output once (+ residual) + weights once
-        eng->conv_bytes.push_back(2.0 * ((double)x.elems() + px * (out_mode == OUT_CONVT && p.fuse_w ? 4.0 : (double)L.cout) * (out_mode == OUT_UPSAMPLE ? (double)(1 << (2 * up_shift)) : 1.0) + (res ? px * (double)L.cout / (double)(1 << (2 * res_shift)) : 0.0) + (double)L.ks * L.ks * L.cin * L.cout));
+        eng->conv_bytes.push_back(2.0 * ((double)x.elems() + px * (out_mode == OUT_CONVT && p.fuse_w ? 4.0 : (double)L.cout) * (out_mode == OUT_UPSAMPLE ? (double)(1 << (2 * up_shift)) : (out_mode == OUT_POOL ? 0.25 : 1.0)) + (res ? px * (double)L.cout / (double)(1 << (2 * res_shift)) : 0.0) + (double)L.ks * L.ks * L.cin * L.cout));
         eng->conv_names.push_back(L.name);
         eng->conv_kernels.push_back(use_pw ? (L.cin == 64 ? "conv_pw_kernel<64>" : "conv_pw_kernel<128>") : conv_kernel_name(cfg));
     }
@@ -283,12 +284,20 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
     tap(eng, "stem.conv1", t1);
     Tensor4 t2 = ws_tensor(eng, B, Hp / 2, Wp / 2, 32);
     RUN(eng_run_conv(eng, D["stem.conv2"], t1, &t2, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "stem.conv2", t2);
-    Tensor4 t3 = ws_tensor(eng, B, Hp / 2, Wp / 2, 64);
-    RUN(eng_run_conv(eng, D["stem.conv3"], t2, &t3, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "stem.conv3", t3);
+    // stem.conv3 + 3x3/s2 max pool: fused (the 64-channel half-resolution tensor, 93 MB per page, is never written) unless the
+    // intermediate is wanted as a tap
+    const bool fuse_pool = eng->fuse_pool && !eng->keep_taps;
+    Tensor4 t3{};
+    if (!fuse_pool || dry) t3 = ws_tensor(eng, B, Hp / 2, Wp / 2, 64);
     Tensor4 x = ws_tensor(eng, B, Hp / 4, Wp / 4, 64);
-    if (!dry && x.p) {
-        hipError_t e = maxpool_launch(t3.p, x.p, B, t3.h, t3.w, 64, 3, 2, 1, x.h, x.w, st);
-        if (e != hipSuccess) return locr_fail(eng, "stem.pool", hipGetErrorString(e));
+    if (fuse_pool) {
+        RUN(eng_run_conv(eng, D["stem.conv3"], t2, &x, nullptr, 0, OUT_POOL, 0, 0, 0, false, st));
+    } else {
+        RUN(eng_run_conv(eng, D["stem.conv3"], t2, &t3, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "stem.conv3", t3);
+        if (!dry && x.p) {
+            hipError_t e = maxpool_launch(t3.p, x.p, B, t3.h, t3.w, 64, 3, 2, 1, x.h, x.w, st);
+            if (e != hipSuccess) return locr_fail(eng, "stem.pool", hipGetErrorString(e));
+        }
     }
     tap(eng, "stem.pool", x);
     const int chs[4] = {64, 128, 256, 512};

@@ -151,3 +151,19 @@ def test_fused_head_equals_unfused(engine, det_weights):
     torch.cuda.synchronize()
     d = (a.float() - b.float()).abs()
     assert float(d.max()) <= 2.0 ** -8 and float((d > 0).float().mean()) < 1e-3   # same sums, order of the 64-term dot differs
+
+
+@pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901), (3, 96, 130)], ids=lambda s: "b%d_%dx%d" % s)
+def test_fused_stem_pool_is_bit_identical(engine, det_weights, shape):
+    """stem.conv3 with the 3x3/s2 max pool in its epilogue (overlapping 16x32 conv tiles, pooled 7x15 per tile, image borders,
+    partial tiles) must reproduce the conv + maxpool kernel pair exactly: same conv arithmetic, max picks existing values."""
+    b, h, w = shape
+    pages = torch.from_numpy(_pages(b, h, w, 33)).cuda()
+    engine.load_det(det_weights)
+    engine.set_option("fuse_pool", 1)
+    a = engine.det_forward(pages).clone()
+    engine.set_option("fuse_pool", 0)
+    ref = engine.det_forward(pages).clone()
+    engine.set_option("fuse_pool", 1)
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref)
