@@ -56,6 +56,7 @@ int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value) {
     else if (!strcmp(key, "fuse_head")) h->fuse_head = value != 0;
     else if (!strcmp(key, "fuse_mb")) h->fuse_mb = value != 0;
     else if (!strcmp(key, "fuse_pool")) h->fuse_pool = value != 0;
+    else if (!strcmp(key, "post_group")) h->post_group = value > 0 ? value : 1;
     else return locr_fail(h, "set_option: unknown key", key);
     return 0;
 }
@@ -89,8 +90,8 @@ int lumina_ocr_det_postprocess(lumina_ocr_t* h, const uint16_t* prob_dev, int ba
     if (!h || !prob_dev || !boxes_dev || !scores_dev || !counts_dev) return locr_fail(h, "det_postprocess", "null argument");
     if (batch <= 0 || max_boxes <= 0 || valid_h > hp || valid_w > wp) return locr_fail(h, "det_postprocess", "bad dimensions");
     API_TRY
-    // pages are processed in groups that bound the workspace
-    const int group = 8;
+    // pages are processed in groups that bound the workspace (~72 MB of labels / row-extreme segments per A4 page)
+    const int group = h->post_group;
     for (int b0 = 0; b0 < batch; b0 += group) {
         const int nb = batch - b0 < group ? batch - b0 : group;
         const size_t need = dbpost_workspace_bytes(nb, hp, wp, max_boxes);

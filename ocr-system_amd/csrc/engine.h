@@ -63,7 +63,7 @@ struct lumina_ocr {
     uint8_t* ws = nullptr; size_t ws_cap = 0, ws_off = 0;
     std::vector<void*> owned;  // device allocations freed at destroy
     bf16_t* zero_block = nullptr;  // 256 B of zeros (out-of-image halo source of the LDS-DMA conv)
-    int det_sub_batch = 16, rec_sub_batch = 4096;
+    int det_sub_batch = 16, rec_sub_batch = 4096, post_group = 64;
     std::map<std::string, Tensor4> taps;  // last forward's intermediates (debug / parity tests)
     bool keep_taps = false;
     bool fuse_head = true;  // head.convt3 fused into head.convt2's epilogue
