@@ -133,7 +133,31 @@ def main():
         bm_cases.append(dict(key=k, value=v, page=pg, key_bbox=kb, value_bbox=vb))
     (OUT / "bbox_matcher.json").write_text(json.dumps(dict(layout=layout, cases=bm_cases)))
 
-    # ---- 6. schema fixture ----
+    # ---- 6. JPEG hand-off: digests of the reference's own encoder calls (compress_for_azure :495-538, image_to_bytes :332-346) ----
+    import io
+
+    def _image(kind, h, w, seed):
+        r = np.random.default_rng(seed)
+        if kind == "noise":
+            return r.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if kind == "ramp":
+            return np.ascontiguousarray((np.linspace(0, 255, w)[None, :, None] * np.ones((h, 1, 3))).astype(np.uint8))
+        return synth.synth_page(h, w, seed, n_lines=max(2, h // 40))[0]
+
+    jcases = []
+    for kind, h, w, seed in [("noise", 1, 1, 1), ("noise", 8, 8, 2), ("noise", 37, 53, 3), ("noise", 64, 48, 4), ("ramp", 17, 31, 5),
+                             ("ramp", 100, 75, 6), ("page", 250, 333, 7), ("page", 640, 448, 8), ("page", 2000, 1414, 9), ("page", 1090, 2000, 10)]:
+        img = _image(kind, h, w, seed)
+        for q in ((95, 85, 30) if h * w < 500000 else (95, 65)):
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, format="JPEG", quality=q, optimize=True)   # the call inside compress_for_azure's loop
+            data = buf.getvalue()
+            if q == 95:
+                assert pre.compress_for_azure(Image.fromarray(img)) == data             # the reference's function itself (fits at q=95)
+            jcases.append(dict(kind=kind, h=h, w=w, seed=seed, quality=q, size=len(data), sha256=hashlib.sha256(data).hexdigest()))
+    (OUT / "jpeg_digests.json").write_text(json.dumps(dict(pillow=Image.__version__ if hasattr(Image, "__version__") else "", cases=jcases), indent=0))
+
+    # ---- 7. schema fixture ----
     shutil.copyfile(REF / "azure_debug_output.json", OUT / "azure_debug_output.json")
     print("golden vectors written to", OUT)
     for p in sorted(OUT.iterdir()):
