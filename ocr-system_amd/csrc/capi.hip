@@ -7,6 +7,7 @@
 #include "engine.h"
 #include "ops.h"
 #include "resize.h"
+#include "jpeg.h"
 #include "stem_conv.h"
 
 #define API_TRY try {
@@ -264,6 +265,25 @@ int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int heigh
     }
     hipError_t e = enhance_launch(img_dev, tmp_dev, out_dev, h->sums, n, height, width, contrast, sharpness, (hipStream_t)stream);
     return e == hipSuccess ? 0 : locr_fail(h, "enhance", hipGetErrorString(e));
+}
+
+int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, uint8_t* out_dev,
+                           size_t out_stride, int32_t* sizes_dev, void* stream) {
+    if (!h || !pages_dev || !out_dev || !sizes_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "jpeg_encode", "bad arguments");
+    API_TRY
+    if (eng_ws_reserve(h, jpeg_workspace_bytes(n, height, width))) return 1;
+    JpegParams p{};
+    p.rgb = pages_dev; p.n = n; p.height = height; p.width = width; p.quality = quality; p.out = out_dev; p.out_stride = out_stride; p.sizes = sizes_dev;
+    hipError_t e = jpeg_encode_launch(p, h->ws, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : locr_fail(h, "jpeg_encode", hipGetErrorString(e));
+    API_CATCH(h)
+}
+
+int lumina_ocr_jpeg_coefficients(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, int16_t* coefs_dev,
+                                 void* stream) {
+    if (!h || !pages_dev || !coefs_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "jpeg_coefficients", "bad arguments");
+    hipError_t e = jpeg_coefficients_launch(pages_dev, n, height, width, quality, coefs_dev, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : locr_fail(h, "jpeg_coefficients", hipGetErrorString(e));
 }
 
 int lumina_ocr_conv_timing_detail(lumina_ocr_t* h, char* buf, size_t cap) {

@@ -1,0 +1,512 @@
+// Baseline JPEG encoder on gfx950, byte-identical to the reference's Pillow call
+//   image.save(buffer, format='JPEG', quality=q, optimize=True)        (/root/reference/backend/utils/image_preprocessing.py:526-538)
+// i.e. libjpeg's integer pipeline: JFIF 1.01, YCbCr 4:2:0, 16-bit fixed-point colour conversion, 2x2 box down-sampling with
+// the alternating 1,2 bias, edge replication inside partial blocks, zero-AC dummy blocks beyond them, "islow" forward DCT,
+// round-half-away quantisation, OPTIMISED Huffman tables (T.81 K.2 with the IJG tie-breaking and 16-bit length limiting),
+// byte stuffing.  Everything runs on the device, stream-ordered, with no host round trip:
+//   1 jpeg_coef      one thread per 8x8 block: RGB -> component samples -> DCT -> quantise -> zig-zag int16        (HBM: 3 B/px in)
+//   2 jpeg_dummy     right / bottom edge MCUs: DC of the dummy luma blocks
+//   3 jpeg_stats     one thread per block: run-length symbols -> per-page histograms (LDS, then global atomics)
+//   4 jpeg_tables    one wave per (page, table): optimal code lengths, length limiting, code assignment
+//   5 jpeg_blockbits one thread per block: coded size in bits;  6 jpeg_scan: exclusive prefix sum per page
+//   7 jpeg_emit      one thread per block: codes OR-ed into the zero-initialised bit stream at the block's bit offset
+//   8 jpeg_finish    one workgroup per page: JFIF / DQT / SOF0 / DHT / SOS headers, 0xFF byte stuffing, EOI, file size
+// Integer arithmetic only: the parallel result is exact by construction (tests/test_gpu_jpeg.py compares files byte for byte).
+#include "jpeg.h"
+
+namespace {
+
+struct Geo { int w, h, mx, my, mcus, ybw, ybh, crows, nblk; };
+struct QTab { uint16_t l[64], c[64]; };  // natural order
+struct DevHT { uint32_t nval; uint8_t bits[17]; uint8_t vals[256]; uint16_t code[256]; uint8_t size[256]; };
+
+__device__ const uint8_t d_ZZ[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
+                                     41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
+                                     15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+constexpr uint8_t STD_LUMA[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57,
+                                  69, 56, 14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55,
+                                  64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+constexpr uint8_t STD_CHROMA[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99,
+                                    99, 99, 47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                    99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+
+// ---- colour conversion (16-bit fixed point; constants = (int)(x * 65536 + 0.5)) ----
+__device__ __forceinline__ int ycc_y(int r, int g, int b) { return (19595 * r + 38470 * g + 7471 * b + 32768) >> 16; }
+__device__ __forceinline__ int ycc_cb(int r, int g, int b) { return (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16; }
+__device__ __forceinline__ int ycc_cr(int r, int g, int b) { return (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16; }
+
+// ---- one 1-D pass of the "islow" DCT over 8 values (PASS 0: rows, result scaled by 4; PASS 1: columns, descaled) ----
+#define JDESC(x, n) (((x) + (1 << ((n)-1))) >> (n))
+template <int PASS>
+__device__ __forceinline__ void dct8(int& d0, int& d1, int& d2, int& d3, int& d4, int& d5, int& d6, int& d7) {
+    constexpr int SH = PASS == 0 ? 11 : 15;
+    const int t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6, t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+    const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    if (PASS == 0) { d0 = (t10 + t11) << 2; d4 = (t10 - t11) << 2; }
+    else { d0 = JDESC(t10 + t11, 2); d4 = JDESC(t10 - t11, 2); }
+    int z1 = (t12 + t13) * 4433;
+    d2 = JDESC(z1 + t13 * 6270, SH);
+    d6 = JDESC(z1 + t12 * (-15137), SH);
+    z1 = t4 + t7;
+    int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+    const int z5 = (z3 + z4) * 9633;
+    const int a4 = t4 * 2446, a5 = t5 * 16819, a6 = t6 * 25172, a7 = t7 * 12299;
+    z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+    z3 += z5; z4 += z5;
+    d7 = JDESC(a4 + z1 + z3, SH);
+    d5 = JDESC(a5 + z2 + z4, SH);
+    d3 = JDESC(a6 + z2 + z3, SH);
+    d1 = JDESC(a7 + z1 + z4, SH);
+}
+
+// ---- 1: samples -> DCT -> quantise -> zig-zag ----
+__global__ __launch_bounds__(256) void jpeg_coef_kernel(const uint8_t* rgb, int n, Geo g, QTab q, int16_t* coefs) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n * g.nblk) return;
+    const int page = (int)(t / g.nblk), rem = (int)(t - (long long)page * g.nblk);
+    const int m = rem / 6, b = rem - m * 6;
+    const int mcx = m % g.mx, mcy = m / g.mx;
+    const uint8_t* img = rgb + (size_t)page * g.h * g.w * 3;
+    uint4* dst = reinterpret_cast<uint4*>(coefs + (size_t)t * 64);
+    int d[64];
+    if (b < 4) {
+        const int bx = 2 * mcx + (b & 1), by = 2 * mcy + (b >> 1);
+        if (bx >= g.ybw || by >= g.ybh) {  // dummy block: zero AC, DC resolved by jpeg_dummy_kernel
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i] = make_uint4(0, 0, 0, 0);
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int y = min(by * 8 + r, g.h - 1);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int x = min(bx * 8 + c, g.w - 1);
+                const uint8_t* px = img + ((size_t)y * g.w + x) * 3;
+                d[r * 8 + c] = ycc_y(px[0], px[1], px[2]) - 128;
+            }
+        }
+    } else {
+        const bool is_cr = b == 5;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int yc = min(mcy * 8 + r, g.crows - 1);   // rows past the last down-sampled row repeat it
+            const int r0 = 2 * yc, r1 = min(2 * yc + 1, g.h - 1);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int xc = mcx * 8 + c;
+                const int c0 = min(2 * xc, g.w - 1), c1 = min(2 * xc + 1, g.w - 1);  // columns are replicated at full resolution
+                int s = (xc & 1) ? 2 : 1;
+                const uint8_t* p00 = img + ((size_t)r0 * g.w + c0) * 3;
+                const uint8_t* p01 = img + ((size_t)r0 * g.w + c1) * 3;
+                const uint8_t* p10 = img + ((size_t)r1 * g.w + c0) * 3;
+                const uint8_t* p11 = img + ((size_t)r1 * g.w + c1) * 3;
+                if (is_cr) s += ycc_cr(p00[0], p00[1], p00[2]) + ycc_cr(p01[0], p01[1], p01[2]) + ycc_cr(p10[0], p10[1], p10[2]) + ycc_cr(p11[0], p11[1], p11[2]);
+                else s += ycc_cb(p00[0], p00[1], p00[2]) + ycc_cb(p01[0], p01[1], p01[2]) + ycc_cb(p10[0], p10[1], p10[2]) + ycc_cb(p11[0], p11[1], p11[2]);
+                d[r * 8 + c] = (s >> 2) - 128;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dct8<0>(d[r * 8], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5], d[r * 8 + 6], d[r * 8 + 7]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dct8<1>(d[c], d[8 + c], d[16 + c], d[24 + c], d[32 + c], d[40 + c], d[48 + c], d[56 + c]);
+    const uint16_t* qt = b < 4 ? q.l : q.c;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const int qv = (int)qt[i] << 3;
+        int v = d[i];
+        if (v < 0) { v = -v + (qv >> 1); v = v >= qv ? v / qv : 0; v = -v; }
+        else { v += qv >> 1; v = v >= qv ? v / qv : 0; }
+        d[i] = v;
+    }
+    constexpr int ZZ[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
+                            41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
+                            15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t wv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[j] = ((uint32_t)d[ZZ[8 * i + 2 * j]] & 0xffffu) | ((uint32_t)d[ZZ[8 * i + 2 * j + 1]] << 16);
+        dst[i] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    }
+}
+
+// ---- 2: DC of dummy luma blocks (right edge: the block to the left; bottom dummy row: the last block of the row above) ----
+__global__ void jpeg_dummy_kernel(int n, Geo g, int16_t* coefs) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * g.mcus) return;
+    const int page = t / g.mcus, m = t - page * g.mcus, mcx = m % g.mx, mcy = m / g.mx;
+    if (mcx != g.mx - 1 && mcy != g.my - 1) return;
+    int16_t* base = coefs + ((size_t)page * g.nblk + (size_t)m * 6) * 64;
+    for (int b = 1; b < 4; ++b) {
+        const int v = b >> 1, bx = 2 * mcx + (b & 1), by = 2 * mcy + v;
+        if (bx < g.ybw && by < g.ybh) continue;
+        base[b * 64] = base[((by < g.ybh) ? b - 1 : v * 2 - 1) * 64];
+    }
+}
+
+__device__ __forceinline__ int nbits_of(int v) { v = v < 0 ? -v : v; return v ? 32 - __clz(v) : 0; }
+__device__ __forceinline__ int prev_dc(const int16_t* pc, int m, int b) {  // pc = the page's coefficients
+    if (b > 0 && b < 4) return pc[((size_t)m * 6 + b - 1) * 64];
+    if (m == 0) return 0;
+    return pc[((size_t)(m - 1) * 6 + (b == 0 ? 3 : b)) * 64];
+}
+
+// ---- 3: symbol statistics: hist[page][4][256]  (0 DC luma, 1 AC luma, 2 DC chroma, 3 AC chroma) ----
+__global__ __launch_bounds__(256) void jpeg_stats_kernel(const int16_t* coefs, Geo g, uint32_t* hist) {
+    __shared__ uint32_t lh[4 * 256];
+    const int page = blockIdx.y, blk = blockIdx.x * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < 1024; i += 256) lh[i] = 0;
+    __syncthreads();
+    if (blk < g.nblk) {
+        const int16_t* pc = coefs + (size_t)page * g.nblk * 64;
+        const int m = blk / 6, b = blk - m * 6, tb = b < 4 ? 0 : 2;
+        __attribute__((aligned(16))) int16_t c[64];
+        const uint4* src = reinterpret_cast<const uint4*>(pc + (size_t)blk * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) reinterpret_cast<uint4*>(c)[i] = src[i];
+        atomicAdd(&lh[tb * 256 + nbits_of((int)c[0] - prev_dc(pc, m, b))], 1u);
+        int r = 0;
+#pragma unroll
+        for (int k = 1; k < 64; ++k) {
+            const int v = c[k];
+            if (v == 0) { ++r; continue; }
+            while (r > 15) { atomicAdd(&lh[(tb + 1) * 256 + 0xF0], 1u); r -= 16; }
+            atomicAdd(&lh[(tb + 1) * 256 + (r << 4) + nbits_of(v)], 1u);
+            r = 0;
+        }
+        if (r > 0) atomicAdd(&lh[(tb + 1) * 256], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 256)
+        if (lh[i]) atomicAdd(&hist[(size_t)page * 1024 + i], lh[i]);
+}
+
+// ---- 4: optimal Huffman table, one wave per (page, table) ----
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), m), hi = __shfl_xor((unsigned)(v >> 32), m);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__global__ __launch_bounds__(64) void jpeg_tables_kernel(const uint32_t* hist, DevHT* tabs) {
+    __shared__ int freq[257], codesize[257], others[257], bits[33];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    for (int i = lane; i < 257; i += 64) { freq[i] = i < 256 ? (int)hist[(size_t)t * 256 + i] : 1; codesize[i] = 0; others[i] = -1; }
+    if (lane < 33) bits[lane] = 0;
+    __syncthreads();
+    const unsigned long long NONE = ~0ull;
+    for (;;) {
+        // smallest non-zero frequency, ties -> the LARGER symbol: key = freq << 16 | (0xFFFF - symbol), minimum wins
+        unsigned long long k1 = NONE;
+        for (int i = lane; i < 257; i += 64) {
+            const int f = freq[i];
+            if (f) { const unsigned long long k = ((unsigned long long)f << 16) | (unsigned)(0xFFFF - i); k1 = k < k1 ? k : k1; }
+        }
+        k1 = wave_min_u64(k1);
+        const int c1 = 0xFFFF - (int)(k1 & 0xFFFF);
+        unsigned long long k2 = NONE;
+        for (int i = lane; i < 257; i += 64) {
+            const int f = freq[i];
+            if (f && i != c1) { const unsigned long long k = ((unsigned long long)f << 16) | (unsigned)(0xFFFF - i); k2 = k < k2 ? k : k2; }
+        }
+        k2 = wave_min_u64(k2);
+        if (k2 == NONE) break;
+        const int c2 = 0xFFFF - (int)(k2 & 0xFFFF);
+        if (lane == 0) {
+            freq[c1] += freq[c2]; freq[c2] = 0;
+            int a = c1;
+            codesize[a]++;
+            while (others[a] >= 0) { a = others[a]; codesize[a]++; }
+            others[a] = c2;
+            a = c2;
+            codesize[a]++;
+            while (others[a] >= 0) { a = others[a]; codesize[a]++; }
+        }
+        __syncthreads();
+    }
+    if (lane != 0) return;
+    for (int i = 0; i <= 256; ++i) if (codesize[i]) bits[codesize[i] > 32 ? 32 : codesize[i]]++;
+    for (int i = 32; i > 16; --i)
+        while (bits[i] > 0) {
+            int j = i - 2;
+            while (bits[j] == 0) --j;
+            bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
+        }
+    int i = 16;
+    while (i > 0 && bits[i] == 0) --i;
+    if (i > 0) bits[i]--;  // the pseudo-symbol 256 reserved the all-ones code
+    DevHT* T = tabs + t;
+    T->bits[0] = 0;
+    for (int k = 1; k <= 16; ++k) T->bits[k] = (uint8_t)bits[k];
+    int p = 0;
+    for (int len = 1; len <= 32; ++len)
+        for (int s = 0; s < 256; ++s) if (codesize[s] == len) T->vals[p++] = (uint8_t)s;
+    T->nval = (uint32_t)p;
+    for (int s = 0; s < 256; ++s) { T->size[s] = 0; T->code[s] = 0; }
+    int k = 0, code = 0;
+    for (int len = 1; len <= 16; ++len) {
+        for (int j = 0; j < bits[len]; ++j, ++k) { T->code[T->vals[k]] = (uint16_t)code++; T->size[T->vals[k]] = (uint8_t)len; }
+        code <<= 1;
+    }
+}
+
+// ---- 5: coded size of every block in bits ----
+__global__ __launch_bounds__(256) void jpeg_blockbits_kernel(const int16_t* coefs, Geo g, const DevHT* tabs, uint32_t* blkbits) {
+    __shared__ uint8_t sz[4 * 256];
+    const int page = blockIdx.y, blk = blockIdx.x * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < 1024; i += 256) sz[i] = tabs[(size_t)page * 4 + (i >> 8)].size[i & 255];
+    __syncthreads();
+    if (blk >= g.nblk) return;
+    const int16_t* pc = coefs + (size_t)page * g.nblk * 64;
+    const int m = blk / 6, b = blk - m * 6, tb = b < 4 ? 0 : 2;
+    __attribute__((aligned(16))) int16_t c[64];
+    const uint4* src = reinterpret_cast<const uint4*>(pc + (size_t)blk * 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) reinterpret_cast<uint4*>(c)[i] = src[i];
+    int nb = nbits_of((int)c[0] - prev_dc(pc, m, b));
+    uint32_t total = sz[tb * 256 + nb] + nb;
+    int r = 0;
+#pragma unroll
+    for (int k = 1; k < 64; ++k) {
+        const int v = c[k];
+        if (v == 0) { ++r; continue; }
+        while (r > 15) { total += sz[(tb + 1) * 256 + 0xF0]; r -= 16; }
+        nb = nbits_of(v);
+        total += sz[(tb + 1) * 256 + (r << 4) + nb] + nb;
+        r = 0;
+    }
+    if (r > 0) total += sz[(tb + 1) * 256];
+    blkbits[(size_t)page * g.nblk + blk] = total;
+}
+
+// ---- 6: exclusive prefix sum of the block sizes of a page (one workgroup per page) -> bit offsets, total bits ----
+__global__ __launch_bounds__(256) void jpeg_scan_kernel(uint32_t* blkbits, Geo g, unsigned long long* totalbits) {
+    __shared__ uint32_t wsum[4];
+    __shared__ unsigned long long run;
+    const int page = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* a = blkbits + (size_t)page * g.nblk;
+    if (tid == 0) run = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < g.nblk; i0 += 256) {
+        const int i = i0 + tid;
+        const uint32_t v = i < g.nblk ? a[i] : 0;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w2 = 0; w2 < wave; ++w2) woff += wsum[w2];
+        const unsigned long long base = run;
+        if (i < g.nblk) a[i] = (uint32_t)(base + woff + inc - v);   // offsets fit 32 bits (checked against the raw capacity in finish)
+        __syncthreads();
+        if (tid == 0) run = base + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) totalbits[page] = run;
+}
+
+// ---- 7: entropy-coded bits, OR-ed into the zeroed stream (big-endian bit order inside big-endian 32-bit words) ----
+struct BitOut {
+    uint32_t* words; unsigned long long pos; unsigned long long cap_bits;
+    __device__ __forceinline__ void put(uint32_t code, int size) {
+        if (size == 0 || pos + size > cap_bits) { pos += size; return; }
+        const unsigned sh = (unsigned)(pos & 31);
+        const unsigned long long v = ((unsigned long long)(code & ((1u << size) - 1u))) << (64 - size - sh);
+        const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+        uint32_t* w = words + (pos >> 5);
+        atomicOr(w, hi);
+        if (lo) atomicOr(w + 1, lo);
+        pos += size;
+    }
+};
+__global__ __launch_bounds__(256) void jpeg_emit_kernel(const int16_t* coefs, Geo g, const DevHT* tabs, const uint32_t* bitoff, uint32_t* raw,
+                                                        size_t raw_words_per_page) {
+    __shared__ uint8_t sz[4 * 256];
+    __shared__ uint16_t cd[4 * 256];
+    const int page = blockIdx.y, blk = blockIdx.x * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < 1024; i += 256) { const DevHT& T = tabs[(size_t)page * 4 + (i >> 8)]; sz[i] = T.size[i & 255]; cd[i] = T.code[i & 255]; }
+    __syncthreads();
+    if (blk >= g.nblk) return;
+    const int16_t* pc = coefs + (size_t)page * g.nblk * 64;
+    const int m = blk / 6, b = blk - m * 6, tb = b < 4 ? 0 : 2;
+    __attribute__((aligned(16))) int16_t c[64];
+    const uint4* src = reinterpret_cast<const uint4*>(pc + (size_t)blk * 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) reinterpret_cast<uint4*>(c)[i] = src[i];
+    BitOut bo{raw + (size_t)page * raw_words_per_page, bitoff[(size_t)page * g.nblk + blk], (unsigned long long)raw_words_per_page * 32 - 32};
+    const int dcd = (int)c[0] - prev_dc(pc, m, b);
+    int nb = nbits_of(dcd);
+    bo.put(((uint32_t)cd[tb * 256 + nb] << nb) | ((uint32_t)(dcd < 0 ? dcd - 1 : dcd) & ((1u << nb) - 1u)), sz[tb * 256 + nb] + nb);
+    int r = 0;
+#pragma unroll
+    for (int k = 1; k < 64; ++k) {
+        const int v = c[k];
+        if (v == 0) { ++r; continue; }
+        while (r > 15) { bo.put(cd[(tb + 1) * 256 + 0xF0], sz[(tb + 1) * 256 + 0xF0]); r -= 16; }
+        nb = nbits_of(v);
+        const int s = (r << 4) + nb;
+        bo.put(((uint32_t)cd[(tb + 1) * 256 + s] << nb) | ((uint32_t)(v < 0 ? v - 1 : v) & ((1u << nb) - 1u)), sz[(tb + 1) * 256 + s] + nb);
+        r = 0;
+    }
+    if (r > 0) bo.put(cd[(tb + 1) * 256], sz[(tb + 1) * 256]);
+}
+
+// ---- 8: headers + byte stuffing + EOI -> the finished file ----
+__global__ __launch_bounds__(256) void jpeg_finish_kernel(const uint32_t* raw, size_t raw_words_per_page, const unsigned long long* totalbits, const DevHT* tabs,
+                                                          Geo g, QTab q, uint8_t* out, size_t out_stride, int32_t* sizes) {
+    __shared__ uint32_t wsum[4];
+    __shared__ unsigned long long run;
+    __shared__ int hdr_len;
+    const int page = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t* o = out + (size_t)page * out_stride;
+    const DevHT* T = tabs + (size_t)page * 4;
+    const unsigned long long tb = totalbits[page];
+    const unsigned long long nbytes = (tb + 7) >> 3;
+    const bool overflow = nbytes + 4 > raw_words_per_page * 4;
+    if (tid == 0) {
+        size_t p = 0;
+        auto put = [&](int v) { if (p < out_stride) o[p] = (uint8_t)v; ++p; };
+        auto put16 = [&](int v) { put(v >> 8); put(v & 0xff); };
+        put(0xFF); put(0xD8);
+        put(0xFF); put(0xE0); put16(16);
+        const uint8_t jf[14] = {'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
+        for (int i = 0; i < 14; ++i) put(jf[i]);
+        for (int t = 0; t < 2; ++t) {
+            put(0xFF); put(0xDB); put16(67); put(t);
+            for (int i = 0; i < 64; ++i) put((t ? q.c : q.l)[d_ZZ[i]]);
+        }
+        put(0xFF); put(0xC0); put16(17); put(8); put16(g.h); put16(g.w); put(3);
+        put(1); put(0x22); put(0); put(2); put(0x11); put(1); put(3); put(0x11); put(1);
+        for (int t = 0; t < 2; ++t)
+            for (int a = 0; a < 2; ++a) {
+                const DevHT& H = T[t * 2 + a];
+                put(0xFF); put(0xC4); put16(2 + 1 + 16 + (int)H.nval); put((a << 4) | t);
+                for (int i = 1; i <= 16; ++i) put(H.bits[i]);
+                for (uint32_t i = 0; i < H.nval; ++i) put(H.vals[i]);
+            }
+        put(0xFF); put(0xDA); put16(12); put(3); put(1); put(0x00); put(2); put(0x11); put(3); put(0x11); put(0); put(63); put(0);
+        hdr_len = (int)p;
+        run = 0;
+    }
+    __syncthreads();
+    const size_t hl = (size_t)hdr_len;
+    const uint32_t* rw = raw + (size_t)page * raw_words_per_page;
+    // each thread: 16 stream bytes per round; 0xFF bytes are followed by a stuffed 0x00
+    for (unsigned long long k0 = 0; k0 < nbytes && !overflow; k0 += 256 * 16) {
+        const unsigned long long kb = k0 + (unsigned long long)tid * 16;
+        uint8_t by[16];
+        uint32_t nff = 0;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+            const unsigned long long wi = (kb >> 2) + wv;
+            uint32_t w = (wi * 4 < nbytes) ? rw[wi] : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned long long k = kb + wv * 4 + j;
+                uint32_t bv = (w >> (24 - 8 * j)) & 0xffu;
+                if (k == nbytes - 1 && (tb & 7)) bv |= 0xffu >> (tb & 7);  // pad the last byte with ones
+                by[wv * 4 + j] = (uint8_t)bv;
+                if (k < nbytes && bv == 0xffu) ++nff;
+            }
+        }
+        uint32_t inc = nff;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t ov = __shfl_up(inc, d); if (lane >= d) inc += ov; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w2 = 0; w2 < wave; ++w2) woff += wsum[w2];
+        const unsigned long long base = run;
+        size_t p = hl + (size_t)kb + (size_t)(base + woff + inc - nff);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (kb + j >= nbytes) break;
+            if (p < out_stride) o[p] = by[j];
+            ++p;
+            if (by[j] == 0xff) { if (p < out_stride) o[p] = 0; ++p; }
+        }
+        __syncthreads();
+        if (tid == 0) run = base + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const unsigned long long total = hl + nbytes + run + 2;
+        size_t p = hl + (size_t)nbytes + (size_t)run;
+        if (p < out_stride) o[p] = 0xFF;
+        if (p + 1 < out_stride) o[p + 1] = 0xD9;
+        sizes[page] = (!overflow && total <= out_stride && total < 0x7fffffffull) ? (int32_t)total : -(int32_t)(total < 0x7fffffffull ? total : 0x7fffffff);
+    }
+}
+
+Geo make_geo(int height, int width) {
+    Geo g;
+    g.w = width; g.h = height; g.mx = (width + 15) / 16; g.my = (height + 15) / 16; g.mcus = g.mx * g.my;
+    g.ybw = (width + 7) / 8; g.ybh = (height + 7) / 8; g.crows = (height + 1) / 2; g.nblk = g.mcus * 6;
+    return g;
+}
+QTab make_qtab(int quality) {
+    QTab q;
+    if (quality <= 0) quality = 1;
+    if (quality > 100) quality = 100;
+    const int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;
+    for (int i = 0; i < 64; ++i) {
+        const long a = ((long)STD_LUMA[i] * scale + 50L) / 100L, b = ((long)STD_CHROMA[i] * scale + 50L) / 100L;
+        q.l[i] = (uint16_t)(a <= 0 ? 1 : (a > 255 ? 255 : a));
+        q.c[i] = (uint16_t)(b <= 0 ? 1 : (b > 255 ? 255 : b));
+    }
+    return q;
+}
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// workspace: coefs | hist | tables | blkbits | totalbits | raw
+size_t jpeg_workspace_bytes(int n, int height, int width) {
+    const Geo g = make_geo(height, width);
+    const size_t coef = al256((size_t)n * g.nblk * 64 * 2), hist = al256((size_t)n * 1024 * 4), tabs = al256((size_t)n * 4 * sizeof(DevHT));
+    const size_t bb = al256((size_t)n * g.nblk * 4), tbits = al256((size_t)n * 8), raw = al256((size_t)n * ((size_t)g.nblk * 128 + 64));
+    return coef + hist + tabs + bb + tbits + raw;
+}
+
+hipError_t jpeg_coefficients_launch(const uint8_t* rgb, int n, int height, int width, int quality, int16_t* coefs, hipStream_t st) {
+    const Geo g = make_geo(height, width);
+    const QTab q = make_qtab(quality);
+    const long long total = (long long)n * g.nblk;
+    hipLaunchKernelGGL(jpeg_coef_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rgb, n, g, q, coefs);
+    hipLaunchKernelGGL(jpeg_dummy_kernel, dim3((n * g.mcus + 255) / 256), dim3(256), 0, st, n, g, coefs);
+    return hipGetLastError();
+}
+
+hipError_t jpeg_encode_launch(const JpegParams& p, void* workspace, hipStream_t st) {
+    if (p.n <= 0 || p.height <= 0 || p.width <= 0 || p.height > 65535 || p.width > 65535) return hipErrorInvalidValue;
+    const Geo g = make_geo(p.height, p.width);
+    const QTab q = make_qtab(p.quality);
+    uint8_t* w = static_cast<uint8_t*>(workspace);
+    auto take = [&](size_t bytes) { void* r = w; w += al256(bytes); return r; };
+    int16_t* coefs = static_cast<int16_t*>(take((size_t)p.n * g.nblk * 64 * 2));
+    uint32_t* hist = static_cast<uint32_t*>(take((size_t)p.n * 1024 * 4));
+    DevHT* tabs = static_cast<DevHT*>(take((size_t)p.n * 4 * sizeof(DevHT)));
+    uint32_t* blkbits = static_cast<uint32_t*>(take((size_t)p.n * g.nblk * 4));
+    unsigned long long* totalbits = static_cast<unsigned long long*>(take((size_t)p.n * 8));
+    const size_t raw_words = ((size_t)g.nblk * 128 + 64) / 4;
+    uint32_t* raw = static_cast<uint32_t*>(take((size_t)p.n * raw_words * 4));
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)p.n * 1024 * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(raw, 0, (size_t)p.n * raw_words * 4, st);
+    if (e != hipSuccess) return e;
+    e = jpeg_coefficients_launch(p.rgb, p.n, p.height, p.width, p.quality, coefs, st);
+    if (e != hipSuccess) return e;
+    const dim3 gb((g.nblk + 255) / 256, p.n);
+    hipLaunchKernelGGL(jpeg_stats_kernel, gb, dim3(256), 0, st, coefs, g, hist);
+    hipLaunchKernelGGL(jpeg_tables_kernel, dim3(p.n * 4), dim3(64), 0, st, hist, tabs);
+    hipLaunchKernelGGL(jpeg_blockbits_kernel, gb, dim3(256), 0, st, coefs, g, tabs, blkbits);
+    hipLaunchKernelGGL(jpeg_scan_kernel, dim3(p.n), dim3(256), 0, st, blkbits, g, totalbits);
+    hipLaunchKernelGGL(jpeg_emit_kernel, gb, dim3(256), 0, st, coefs, g, tabs, blkbits, raw, raw_words);
+    hipLaunchKernelGGL(jpeg_finish_kernel, dim3(p.n), dim3(256), 0, st, raw, raw_words, totalbits, tabs, g, q, p.out, p.out_stride, p.sizes);
+    return hipGetLastError();
+}

@@ -65,6 +65,8 @@ def load_library() -> ctypes.CDLL:
         "lumina_ocr_conv_timing_detail": (i32, [vp, c.c_char_p, sz]),
         "lumina_ocr_resize_lanczos": (i32, [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
         "lumina_ocr_enhance": (i32, [vp, vp, i32, i32, i32, f32, f32, vp, vp, vp]),
+        "lumina_ocr_jpeg_encode": (i32, [vp, vp, i32, i32, i32, i32, vp, sz, vp, vp]),
+        "lumina_ocr_jpeg_coefficients": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
     }
     missing = []
     for name, (res, args) in sig.items():
@@ -85,7 +87,7 @@ EXPORTED_SYMBOLS = [
     "lumina_ocr_load_det_weights", "lumina_ocr_load_rec_weights", "lumina_ocr_num_classes", "lumina_ocr_normalize",
     "lumina_ocr_det_forward", "lumina_ocr_det_postprocess", "lumina_ocr_rec_crop", "lumina_ocr_rec_forward",
     "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing", "lumina_ocr_conv_timing_detail",
-    "lumina_ocr_resize_lanczos", "lumina_ocr_enhance",
+    "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients",
 ]
 
 
@@ -135,6 +137,27 @@ class Engine:
 
     def _stream(self) -> int:
         return _torch().cuda.current_stream().cuda_stream
+
+    def jpeg_encode(self, pages, quality: int = 95, max_bytes: int = 2 * 1024 * 1024):
+        """uint8 [n,H,W,3] device -> (files uint8 [n, stride] device, sizes int32 [n] device); sizes[i] < 0: file i needs more than
+        max_bytes (the reference's cue to lower the quality).  Asynchronous; byte-identical to PIL save(JPEG, quality, optimize=True)."""
+        torch = _torch()
+        n, h, w, c = pages.shape
+        assert c == 3 and pages.dtype == torch.uint8
+        stride = (int(max_bytes) + 1023) // 1024 * 1024
+        out = torch.empty((n, stride), dtype=torch.uint8, device=pages.device)
+        sizes = torch.empty((n,), dtype=torch.int32, device=pages.device)
+        self._chk(self.lib.lumina_ocr_jpeg_encode(self._h, _ptr(pages), n, h, w, int(quality), _ptr(out), stride, _ptr(sizes),
+                                                  self._stream()))
+        return out, sizes
+
+    def jpeg_coefficients(self, pages, quality: int = 95):
+        torch = _torch()
+        n, h, w, _ = pages.shape
+        mcus = ((w + 15) // 16) * ((h + 15) // 16)
+        coefs = torch.empty((n, mcus, 6, 64), dtype=torch.int16, device=pages.device)
+        self._chk(self.lib.lumina_ocr_jpeg_coefficients(self._h, _ptr(pages), n, h, w, int(quality), _ptr(coefs), self._stream()))
+        return coefs
 
     def set_option(self, key: str, value: int):
         self._chk(self.lib.lumina_ocr_set_option(self._h, key.encode(), int(value)))
