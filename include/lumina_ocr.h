@@ -96,9 +96,11 @@ int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int heigh
  * ocr_service.py:459, saved by backend/utils/file_manager.py:283-287).  Byte-identical to Pillow's output: JFIF 1.01, YCbCr 4:2:0,
  * integer DCT, optimised Huffman tables.  pages_dev: uint8 [n, height, width, 3]; out_dev: uint8 [n, out_stride] receives one complete
  * file per page; sizes_dev[i] = its length, or a negative number (-(length needed), saturated) when it does not fit out_stride — the
- * caller's cue to retry at a lower quality, as the reference's loop does when a file exceeds its 2 MB target.  Asynchronous on stream. */
-int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, uint8_t* out_dev,
-                           size_t out_stride, int32_t* sizes_dev, void* stream);
+ * caller's cue to retry at a lower quality, as the reference's loop does when a file exceeds its 2 MB target.  optimize = 0 writes
+ * the typical Huffman tables of T.81 Annex K.3 instead (the reference's size probe `image.save(buffer, 'JPEG', quality=min_quality)`,
+ * :548).  Asynchronous on stream. */
+int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, int optimize,
+                           uint8_t* out_dev, size_t out_stride, int32_t* sizes_dev, void* stream);
 /* Parity hook for the encoder's first half: quantised DCT coefficients, int16 [n][ceil(w/16)*ceil(h/16)][6][64] in zig-zag order
  * (4 luma, Cb, Cr blocks per MCU; dummy edge blocks resolved). */
 int lumina_ocr_jpeg_coefficients(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, int16_t* coefs_dev,

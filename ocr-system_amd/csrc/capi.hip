@@ -267,13 +267,13 @@ int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int heigh
     return e == hipSuccess ? 0 : locr_fail(h, "enhance", hipGetErrorString(e));
 }
 
-int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, uint8_t* out_dev,
-                           size_t out_stride, int32_t* sizes_dev, void* stream) {
+int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, int optimize,
+                           uint8_t* out_dev, size_t out_stride, int32_t* sizes_dev, void* stream) {
     if (!h || !pages_dev || !out_dev || !sizes_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "jpeg_encode", "bad arguments");
     API_TRY
     if (eng_ws_reserve(h, jpeg_workspace_bytes(n, height, width))) return 1;
     JpegParams p{};
-    p.rgb = pages_dev; p.n = n; p.height = height; p.width = width; p.quality = quality; p.out = out_dev; p.out_stride = out_stride; p.sizes = sizes_dev;
+    p.rgb = pages_dev; p.n = n; p.height = height; p.width = width; p.quality = quality; p.optimize = optimize != 0; p.out = out_dev; p.out_stride = out_stride; p.sizes = sizes_dev;
     hipError_t e = jpeg_encode_launch(p, h->ws, (hipStream_t)stream);
     return e == hipSuccess ? 0 : locr_fail(h, "jpeg_encode", hipGetErrorString(e));
     API_CATCH(h)

@@ -8,6 +8,7 @@
 struct JpegParams {
     const uint8_t* rgb;   // [n, height, width, 3] u8, device
     int n, height, width, quality;
+    int optimize;         // 1: per-page optimal Huffman tables (PIL optimize=True); 0: the Annex K.3 typical tables
     uint8_t* out;         // [n, out_stride] device: complete JFIF files
     size_t out_stride;
     int32_t* sizes;       // [n] device: file length in bytes, or -(needed length) when it exceeds out_stride

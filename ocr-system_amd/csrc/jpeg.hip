@@ -255,6 +255,61 @@ __global__ __launch_bounds__(64) void jpeg_tables_kernel(const uint32_t* hist, D
     }
 }
 
+// ---- 4': the ITU-T T.81 Annex K.3 typical tables (optimize == 0: what libjpeg writes without the statistics pass) ----
+__device__ const uint8_t d_STD_BITS_DC_L[17] = {
+    0x00, 0x00, 0x01, 0x05, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00,
+};
+__device__ const uint8_t d_STD_VALS_DC_L[12] = {
+    0x00, 0x01, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x09, 0x0a, 0x0b,
+};
+__device__ const uint8_t d_STD_BITS_AC_L[17] = {
+    0x00, 0x00, 0x02, 0x01, 0x03, 0x03, 0x02, 0x04, 0x03, 0x05, 0x05, 0x04, 0x04, 0x00, 0x00, 0x01, 0x7d,
+};
+__device__ const uint8_t d_STD_VALS_AC_L[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08,
+    0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28,
+    0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+    0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89,
+    0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6,
+    0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa,
+};
+__device__ const uint8_t d_STD_BITS_DC_C[17] = {
+    0x00, 0x00, 0x03, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x00, 0x00, 0x00, 0x00, 0x00,
+};
+__device__ const uint8_t d_STD_VALS_DC_C[12] = {
+    0x00, 0x01, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x09, 0x0a, 0x0b,
+};
+__device__ const uint8_t d_STD_BITS_AC_C[17] = {
+    0x00, 0x00, 0x02, 0x01, 0x02, 0x04, 0x04, 0x03, 0x04, 0x07, 0x05, 0x04, 0x04, 0x00, 0x01, 0x02, 0x77,
+};
+__device__ const uint8_t d_STD_VALS_AC_C[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91,
+    0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26,
+    0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
+    0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87,
+    0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4,
+    0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+    0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa,
+};
+__global__ __launch_bounds__(64) void jpeg_std_tables_kernel(DevHT* tabs) {
+    if (threadIdx.x != 0) return;
+    const int t = blockIdx.x & 3;   // 0 DC luma, 1 AC luma, 2 DC chroma, 3 AC chroma
+    const uint8_t* bits = t == 0 ? d_STD_BITS_DC_L : (t == 1 ? d_STD_BITS_AC_L : (t == 2 ? d_STD_BITS_DC_C : d_STD_BITS_AC_C));
+    const uint8_t* vals = t == 0 ? d_STD_VALS_DC_L : (t == 1 ? d_STD_VALS_AC_L : (t == 2 ? d_STD_VALS_DC_C : d_STD_VALS_AC_C));
+    const int nv = (t & 1) ? 162 : 12;
+    DevHT* T = tabs + blockIdx.x;
+    for (int k = 0; k <= 16; ++k) T->bits[k] = bits[k];
+    for (int k = 0; k < nv; ++k) T->vals[k] = vals[k];
+    T->nval = (uint32_t)nv;
+    for (int s2 = 0; s2 < 256; ++s2) { T->size[s2] = 0; T->code[s2] = 0; }
+    int k = 0, code = 0;
+    for (int len = 1; len <= 16; ++len) {
+        for (int j = 0; j < bits[len]; ++j, ++k) { T->code[vals[k]] = (uint16_t)code++; T->size[vals[k]] = (uint8_t)len; }
+        code <<= 1;
+    }
+}
+
 // ---- 5: coded size of every block in bits ----
 __global__ __launch_bounds__(256) void jpeg_blockbits_kernel(const int16_t* coefs, Geo g, const DevHT* tabs, uint32_t* blkbits) {
     __shared__ uint8_t sz[4 * 256];
@@ -502,8 +557,12 @@ hipError_t jpeg_encode_launch(const JpegParams& p, void* workspace, hipStream_t 
     e = jpeg_coefficients_launch(p.rgb, p.n, p.height, p.width, p.quality, coefs, st);
     if (e != hipSuccess) return e;
     const dim3 gb((g.nblk + 255) / 256, p.n);
-    hipLaunchKernelGGL(jpeg_stats_kernel, gb, dim3(256), 0, st, coefs, g, hist);
-    hipLaunchKernelGGL(jpeg_tables_kernel, dim3(p.n * 4), dim3(64), 0, st, hist, tabs);
+    if (p.optimize) {
+        hipLaunchKernelGGL(jpeg_stats_kernel, gb, dim3(256), 0, st, coefs, g, hist);
+        hipLaunchKernelGGL(jpeg_tables_kernel, dim3(p.n * 4), dim3(64), 0, st, hist, tabs);
+    } else {
+        hipLaunchKernelGGL(jpeg_std_tables_kernel, dim3(p.n * 4), dim3(64), 0, st, tabs);
+    }
     hipLaunchKernelGGL(jpeg_blockbits_kernel, gb, dim3(256), 0, st, coefs, g, tabs, blkbits);
     hipLaunchKernelGGL(jpeg_scan_kernel, dim3(p.n), dim3(256), 0, st, blkbits, g, totalbits);
     hipLaunchKernelGGL(jpeg_emit_kernel, gb, dim3(256), 0, st, coefs, g, tabs, blkbits, raw, raw_words);

@@ -65,7 +65,7 @@ def load_library() -> ctypes.CDLL:
         "lumina_ocr_conv_timing_detail": (i32, [vp, c.c_char_p, sz]),
         "lumina_ocr_resize_lanczos": (i32, [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
         "lumina_ocr_enhance": (i32, [vp, vp, i32, i32, i32, f32, f32, vp, vp, vp]),
-        "lumina_ocr_jpeg_encode": (i32, [vp, vp, i32, i32, i32, i32, vp, sz, vp, vp]),
+        "lumina_ocr_jpeg_encode": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
         "lumina_ocr_jpeg_coefficients": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
     }
     missing = []
@@ -138,7 +138,7 @@ class Engine:
     def _stream(self) -> int:
         return _torch().cuda.current_stream().cuda_stream
 
-    def jpeg_encode(self, pages, quality: int = 95, max_bytes: int = 2 * 1024 * 1024):
+    def jpeg_encode(self, pages, quality: int = 95, max_bytes: int = 2 * 1024 * 1024, optimize: bool = True):
         """uint8 [n,H,W,3] device -> (files uint8 [n, stride] device, sizes int32 [n] device); sizes[i] < 0: file i needs more than
         max_bytes (the reference's cue to lower the quality).  Asynchronous; byte-identical to PIL save(JPEG, quality, optimize=True)."""
         torch = _torch()
@@ -147,7 +147,7 @@ class Engine:
         stride = (int(max_bytes) + 1023) // 1024 * 1024
         out = torch.empty((n, stride), dtype=torch.uint8, device=pages.device)
         sizes = torch.empty((n,), dtype=torch.int32, device=pages.device)
-        self._chk(self.lib.lumina_ocr_jpeg_encode(self._h, _ptr(pages), n, h, w, int(quality), _ptr(out), stride, _ptr(sizes),
+        self._chk(self.lib.lumina_ocr_jpeg_encode(self._h, _ptr(pages), n, h, w, int(quality), int(bool(optimize)), _ptr(out), stride, _ptr(sizes),
                                                   self._stream()))
         return out, sizes
 

@@ -142,12 +142,11 @@ class OCRService:
             raise ValueError("height and width must be > 0")
         return np.ascontiguousarray(np.asarray(image, np.uint8))
 
-    def _finish_page(self, det, processed_hwc: np.ndarray, page_number: int, original_size, t0: float) -> OCROutput:
+    def _finish_page(self, det, jpeg: bytes, processed_hw, page_number: int, original_size, t0: float) -> OCROutput:
         merged, ordered = layout.reading_order(det.triples())
         md = layout.page_markdown(merged)
         boxes = layout.build_layout_boxes(ordered, page_number)
-        jpeg = self._pre.compress_for_azure(Image.fromarray(processed_hwc))
-        ph, pw = processed_hwc.shape[:2]
+        ph, pw = processed_hw
         return OCROutput(markdown=md, html=layout.html_from_markdown(md),
                          json_output={"page_count": 1, "words_count": sum(1 for b in boxes if b["type"] == "word"),
                                       "lines_count": len(ordered), "tables_count": 0, "paragraphs_count": 0},
@@ -164,7 +163,8 @@ class OCRService:
                 self._ensure_engine()
                 arr = self._prepare(image)
                 dets, processed = self._pipeline.run(torch.from_numpy(arr.copy())[None].cuda())
-                return self._finish_page(dets[0], processed[0].cpu().numpy(), page_number, original_size, t0)
+                jpeg = self._pre.compress_for_azure_device(processed)[0]   # processed_image_bytes: encoded on the device
+                return self._finish_page(dets[0], jpeg, tuple(processed.shape[1:3]), page_number, original_size, t0)
             except Exception as e:  # errors are data (:464-475)
                 logger.error("OCR failed: %s", e)
                 return OCROutput(success=False, error=str(e), processing_time_ms=_ms_since(t0), page_number=page_number,
@@ -196,9 +196,9 @@ class OCRService:
                     self._ensure_engine()
                     batch = np.stack([self._prepare(images[i]) for i in idxs])
                     dets, processed = self._pipeline.run(torch.from_numpy(batch).cuda())
-                    proc_h = processed.cpu().numpy()
+                    jpegs = self._pre.compress_for_azure_device(processed)
                     for j, i in enumerate(idxs):
-                        out[i] = self._finish_page(dets[j], proc_h[j], first_page_number + i, images[i].size, t0)
+                        out[i] = self._finish_page(dets[j], jpegs[j], tuple(processed.shape[1:3]), first_page_number + i, images[i].size, t0)
                 except Exception as e:
                     for i in idxs:
                         out[i] = OCROutput(success=False, error=str(e), processing_time_ms=_ms_since(t0),

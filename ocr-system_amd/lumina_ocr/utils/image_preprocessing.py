@@ -111,6 +111,42 @@ class ImagePreprocessor:
         small.save(buf, format="JPEG", quality=min_quality, optimize=True)
         return buf.getvalue()
 
+    def compress_for_azure_device(self, pages, target_size_mb: float = 2.0, initial_quality: int = 95, min_quality: int = 30) -> List[bytes]:
+        """compress_for_azure (:495-557) for a batch of processed pages that are already on the device (uint8 [n,H,W,3]):
+        the same quality loop — 95, 85, ... down to min_quality until a page's file fits target_size_mb — with every encode done by
+        the engine (lumina_ocr_jpeg_encode, byte-identical to the PIL call inside the reference's loop); pages that still do not
+        fit are LANCZOS-resized on the device by sqrt(target / size) and encoded at min_quality, as the reference does."""
+        eng = self._eng()
+        target = int(target_size_mb * 1024 * 1024)
+        n = pages.shape[0]
+        result: List[Optional[bytes]] = [None] * n
+        todo = list(range(n))
+        q = initial_quality
+        while todo and q >= min_quality:
+            sub = pages if len(todo) == n else pages[todo]
+            files, sizes = eng.jpeg_encode(sub, q, max_bytes=target)
+            sizes_h = sizes.cpu().numpy()
+            fit = [k for k in range(len(todo)) if 0 < sizes_h[k] <= target]
+            if fit:
+                files_h = files[fit].cpu().numpy()
+                for j, k in enumerate(fit):
+                    result[todo[k]] = files_h[j, : sizes_h[k]].tobytes()
+            todo = [todo[k] for k in range(len(todo)) if not (0 < sizes_h[k] <= target)]
+            q -= 10
+        for i in todo:  # quality reduction was not enough: also resize (:540-557)
+            page = pages[i:i + 1]
+            h, w = int(page.shape[1]), int(page.shape[2])
+            _, probe = eng.jpeg_encode(page, min_quality, max_bytes=target, optimize=False)   # size probe WITHOUT optimised tables (:548)
+            current = abs(int(probe[0]))
+            scale = (target / current) ** 0.5
+            small = eng.resize_lanczos(page, int(h * scale), int(w * scale))
+            files, sizes = eng.jpeg_encode(small, min_quality, max_bytes=2 * target)
+            sz = int(sizes[0])
+            if sz <= 0:
+                raise ValueError("resized page still exceeds twice the JPEG size target")
+            result[i] = files[0, :sz].cpu().numpy().tobytes()
+        return result  # type: ignore[return-value]
+
     def pdf_to_images(self, pdf_path: Union[str, Path], dpi: Optional[int] = None) -> List[Image.Image]:
         """:248-295 — needs pdf2image + poppler exactly like the reference; absent here -> ImportError as data upstream."""
         try:

@@ -176,6 +176,44 @@ int oracle_jpeg_coefficients(const uint8_t* rgb, int w, int h, int quality, int1
 }
 
 /* ---- Huffman ---- */
+/* ITU-T T.81 Annex K.3 typical tables: what libjpeg writes when optimize is off (the reference's size probe, :548) */
+static const uint8_t STD_BITS_DC_L[17] = {
+    0x00, 0x00, 0x01, 0x05, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00,
+};
+static const uint8_t STD_VALS_DC_L[12] = {
+    0x00, 0x01, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x09, 0x0a, 0x0b,
+};
+static const uint8_t STD_BITS_AC_L[17] = {
+    0x00, 0x00, 0x02, 0x01, 0x03, 0x03, 0x02, 0x04, 0x03, 0x05, 0x05, 0x04, 0x04, 0x00, 0x00, 0x01, 0x7d,
+};
+static const uint8_t STD_VALS_AC_L[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08,
+    0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28,
+    0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+    0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89,
+    0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6,
+    0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa,
+};
+static const uint8_t STD_BITS_DC_C[17] = {
+    0x00, 0x00, 0x03, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x00, 0x00, 0x00, 0x00, 0x00,
+};
+static const uint8_t STD_VALS_DC_C[12] = {
+    0x00, 0x01, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x09, 0x0a, 0x0b,
+};
+static const uint8_t STD_BITS_AC_C[17] = {
+    0x00, 0x00, 0x02, 0x01, 0x02, 0x04, 0x04, 0x03, 0x04, 0x07, 0x05, 0x04, 0x04, 0x00, 0x01, 0x02, 0x77,
+};
+static const uint8_t STD_VALS_AC_C[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91,
+    0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26,
+    0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
+    0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87,
+    0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4,
+    0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+    0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa,
+};
+
 typedef struct { uint8_t bits[17]; uint8_t val[256]; uint16_t code[256]; uint8_t size[256]; } HT;
 
 static int nbits_of(int v) { int n = 0; if (v < 0) v = -v; while (v) { ++n; v >>= 1; } return n; }
@@ -250,7 +288,12 @@ static void put_u16(BW* b, int v) { put_byte(b, (v >> 8) & 0xff); put_byte(b, v 
 
 /* Full encoder: RGB (interleaved, w x h) -> JFIF byte stream identical to Pillow's save(format='JPEG', quality, optimize=True).
  * Returns the stream length (may exceed cap: then only cap bytes were written). */
+size_t oracle_jpeg_encode_ex(const uint8_t* rgb, int w, int h, int quality, int optimize, uint8_t* out, size_t cap);
 size_t oracle_jpeg_encode(const uint8_t* rgb, int w, int h, int quality, uint8_t* out, size_t cap) {
+    return oracle_jpeg_encode_ex(rgb, w, h, quality, 1, out, cap);
+}
+/* optimize != 0: two-pass optimal tables; optimize == 0: the Annex K.3 tables */
+size_t oracle_jpeg_encode_ex(const uint8_t* rgb, int w, int h, int quality, int optimize, uint8_t* out, size_t cap) {
     const int mx = (w + 15) / 16, my = (h + 15) / 16, mcus = mx * my;
     int16_t* coefs = (int16_t*)malloc((size_t)mcus * 6 * 64 * sizeof(int16_t));
     oracle_jpeg_coefficients(rgb, w, h, quality, coefs);
@@ -277,8 +320,14 @@ size_t oracle_jpeg_encode(const uint8_t* rgb, int w, int h, int quality, uint8_t
     HT dc[2], ac[2];
     int ndc[2], nac[2];
     for (int t = 0; t < 2; ++t) {
-        oracle_jpeg_gen_table(dcf[t], dc[t].bits, dc[t].val, &ndc[t]); derive(&dc[t], ndc[t]);
-        oracle_jpeg_gen_table(acf[t], ac[t].bits, ac[t].val, &nac[t]); derive(&ac[t], nac[t]);
+        if (optimize) {
+            oracle_jpeg_gen_table(dcf[t], dc[t].bits, dc[t].val, &ndc[t]);
+            oracle_jpeg_gen_table(acf[t], ac[t].bits, ac[t].val, &nac[t]);
+        } else {
+            memcpy(dc[t].bits, t ? STD_BITS_DC_C : STD_BITS_DC_L, 17); memcpy(dc[t].val, t ? STD_VALS_DC_C : STD_VALS_DC_L, 12); ndc[t] = 12;
+            memcpy(ac[t].bits, t ? STD_BITS_AC_C : STD_BITS_AC_L, 17); memcpy(ac[t].val, t ? STD_VALS_AC_C : STD_VALS_AC_L, 162); nac[t] = 162;
+        }
+        derive(&dc[t], ndc[t]); derive(&ac[t], nac[t]);
     }
     /* headers */
     BW bw = {out, 0, cap, 0, 0};

@@ -8,15 +8,15 @@ import numpy as np
 from .dbpost import lib as _lib
 
 
-def encode(rgb: np.ndarray, quality: int = 95) -> bytes:
-    """uint8 [H,W,3] -> the JFIF byte stream of PIL's save(format='JPEG', quality=quality, optimize=True)."""
+def encode(rgb: np.ndarray, quality: int = 95, optimize: bool = True) -> bytes:
+    """uint8 [H,W,3] -> the JFIF byte stream of PIL's save(format='JPEG', quality=quality, optimize=optimize)."""
     a = np.ascontiguousarray(rgb, np.uint8)
     h, w, _ = a.shape
     L = _lib()
-    L.oracle_jpeg_encode.restype = ctypes.c_size_t
+    L.oracle_jpeg_encode_ex.restype = ctypes.c_size_t
     cap = w * h * 3 + 65536
     out = np.empty(cap, np.uint8)
-    n = L.oracle_jpeg_encode(a.ctypes.data_as(ctypes.c_void_p), w, h, int(quality), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cap))
+    n = L.oracle_jpeg_encode_ex(a.ctypes.data_as(ctypes.c_void_p), w, h, int(quality), int(bool(optimize)), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cap))
     assert n <= cap
     return out[:n].tobytes()
 

@@ -55,3 +55,36 @@ def test_too_small_output_reports_negative_size(engine):
     imgs = _images(1, 200, 300, 5, "noise")
     out, sizes = engine.jpeg_encode(torch.from_numpy(imgs).cuda(), 95, max_bytes=4096)
     assert int(sizes[0]) < 0
+
+
+@pytest.mark.parametrize("quality", [95, 30])
+def test_standard_table_mode_matches_pillow(engine, quality):
+    """optimize=0: the Annex K.3 tables — the reference's size probe `image.save(buffer, 'JPEG', quality=min_quality)` (:548)."""
+    from PIL import Image
+    from oracle import jpeg as oj
+    imgs = _images(2, 123, 211, 31, "page")
+    out, sizes = engine.jpeg_encode(torch.from_numpy(imgs).cuda(), quality, optimize=False)
+    out, sizes = out.cpu().numpy(), sizes.cpu().numpy()
+    for i in range(2):
+        b = io.BytesIO()
+        Image.fromarray(imgs[i]).save(b, format="JPEG", quality=quality)
+        got = out[i, : sizes[i]].tobytes()
+        assert got == b.getvalue() and got == oj.encode(imgs[i], quality, optimize=False)
+
+
+def test_compress_for_azure_device_mirrors_the_reference_loop(engine):
+    """Quality loop 95 -> 30 and the resize fallback (image_preprocessing.py:495-557) on the device vs the same loop run with PIL."""
+    from PIL import Image
+    from lumina_ocr.utils.image_preprocessing import ImagePreprocessor
+    pre = ImagePreprocessor(engine=engine)
+    rng = np.random.default_rng(8)
+    page = synth.synth_page(400, 560, 3, n_lines=10)[0]
+    noisy = np.clip(page.astype(np.int16) + rng.normal(0, 12, page.shape), 0, 255).astype(np.uint8)
+    batch = np.stack([page, noisy])
+    dev = torch.from_numpy(batch).cuda()
+    full = [len(pre.compress_for_azure(Image.fromarray(b))) for b in batch]
+    for target in (2.0, max(full) * 0.7 / 2 ** 20, min(full) * 0.45 / 2 ** 20, 0.004):   # fits / lower quality / mixed / resize fallback
+        got = pre.compress_for_azure_device(dev, target_size_mb=target)
+        for i in range(2):
+            ref = pre.compress_for_azure(Image.fromarray(batch[i]), target_size_mb=target)
+            assert got[i] == ref, (target, i, len(got[i]), len(ref))
