@@ -367,17 +367,32 @@ __global__ __launch_bounds__(256) void jpeg_scan_kernel(uint32_t* blkbits, Geo g
 }
 
 // ---- 7: entropy-coded bits, OR-ed into the zeroed stream (big-endian bit order inside big-endian 32-bit words) ----
+// A block's bits are contiguous, so only its first and last 32-bit words are shared with the neighbouring blocks: those two are
+// OR-ed atomically into the zeroed stream, every word in between is owned by this thread and stored plainly.
 struct BitOut {
     uint32_t* words; unsigned long long pos; unsigned long long cap_bits;
+    unsigned long long acc; int nacc; bool first;   // acc: pending bits, left-aligned at bit 63; nacc counts them (incl. the lead-in)
+    __device__ __forceinline__ void begin() { nacc = (int)(pos & 31); acc = 0; first = true; pos &= ~31ull; }
+    __device__ __forceinline__ void flush_word() {  // emit the top 32 bits of acc at word pos/32
+        if (pos + 32 <= cap_bits) {
+            uint32_t* w = words + (pos >> 5);
+            const uint32_t v = (uint32_t)(acc >> 32);
+            if (first) { if (v) atomicOr(w, v); first = false; }
+            else *w = v;
+        }
+        acc <<= 32; nacc -= 32; pos += 32;
+    }
     __device__ __forceinline__ void put(uint32_t code, int size) {
-        if (size == 0 || pos + size > cap_bits) { pos += size; return; }
-        const unsigned sh = (unsigned)(pos & 31);
-        const unsigned long long v = ((unsigned long long)(code & ((1u << size) - 1u))) << (64 - size - sh);
-        const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
-        uint32_t* w = words + (pos >> 5);
-        atomicOr(w, hi);
-        if (lo) atomicOr(w + 1, lo);
-        pos += size;
+        if (size == 0) return;
+        acc |= ((unsigned long long)(code & ((1u << size) - 1u))) << (64 - size - nacc);
+        nacc += size;
+        if (nacc >= 32) flush_word();
+    }
+    __device__ __forceinline__ void end() {
+        if (nacc > 0 && pos + 32 <= cap_bits) {
+            const uint32_t v = (uint32_t)(acc >> 32);
+            if (v) atomicOr(words + (pos >> 5), v);
+        }
     }
 };
 __global__ __launch_bounds__(256) void jpeg_emit_kernel(const int16_t* coefs, Geo g, const DevHT* tabs, const uint32_t* bitoff, uint32_t* raw,
@@ -394,7 +409,8 @@ __global__ __launch_bounds__(256) void jpeg_emit_kernel(const int16_t* coefs, Ge
     const uint4* src = reinterpret_cast<const uint4*>(pc + (size_t)blk * 64);
 #pragma unroll
     for (int i = 0; i < 8; ++i) reinterpret_cast<uint4*>(c)[i] = src[i];
-    BitOut bo{raw + (size_t)page * raw_words_per_page, bitoff[(size_t)page * g.nblk + blk], (unsigned long long)raw_words_per_page * 32 - 32};
+    BitOut bo{raw + (size_t)page * raw_words_per_page, bitoff[(size_t)page * g.nblk + blk], (unsigned long long)raw_words_per_page * 32 - 32, 0, 0, true};
+    bo.begin();
     const int dcd = (int)c[0] - prev_dc(pc, m, b);
     int nb = nbits_of(dcd);
     bo.put(((uint32_t)cd[tb * 256 + nb] << nb) | ((uint32_t)(dcd < 0 ? dcd - 1 : dcd) & ((1u << nb) - 1u)), sz[tb * 256 + nb] + nb);
@@ -410,6 +426,7 @@ __global__ __launch_bounds__(256) void jpeg_emit_kernel(const int16_t* coefs, Ge
         r = 0;
     }
     if (r > 0) bo.put(cd[(tb + 1) * 256], sz[(tb + 1) * 256]);
+    bo.end();
 }
 
 // ---- 8: headers + byte stuffing + EOI -> the finished file ----
