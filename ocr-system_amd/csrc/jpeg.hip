@@ -13,6 +13,7 @@
 //   8 jpeg_finish    one workgroup per page: JFIF / DQT / SOF0 / DHT / SOS headers, 0xFF byte stuffing, EOI, file size
 // Integer arithmetic only: the parallel result is exact by construction (tests/test_gpu_jpeg.py compares files byte for byte).
 #include "jpeg.h"
+#include "lds_rows.h"
 
 namespace {
 
@@ -59,15 +60,50 @@ __device__ __forceinline__ void dct8(int& d0, int& d1, int& d2, int& d3, int& d4
     d1 = JDESC(a7 + z1 + z4, SH);
 }
 
-// ---- 1: samples -> DCT -> quantise -> zig-zag ----
+// ---- 1: samples -> DCT -> quantise -> zig-zag.  One workgroup = 16 MCUs of one MCU row (256 x 16 pixels) ----
+//   a) the RGB rows go to LDS with aligned word loads (lds_rows.h);  b) all 256 threads convert: Y for every pixel, Cb / Cr for
+//   every 2x2 quad (edge replication = clamped tile coordinates), into planar u8 tiles;  c) 96 threads (16 MCUs x 6 blocks)
+//   read their 8x8 samples as 8-byte rows, run the DCT in registers, quantise and store the zig-zag block.
+constexpr int JT_PX = 256, JT_PITCH = (JT_PX * 3 + 3) / 4 + 2;
 __global__ __launch_bounds__(256) void jpeg_coef_kernel(const uint8_t* rgb, int n, Geo g, QTab q, int16_t* coefs) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)n * g.nblk) return;
-    const int page = (int)(t / g.nblk), rem = (int)(t - (long long)page * g.nblk);
-    const int m = rem / 6, b = rem - m * 6;
-    const int mcx = m % g.mx, mcy = m / g.mx;
-    const uint8_t* img = rgb + (size_t)page * g.h * g.w * 3;
-    uint4* dst = reinterpret_cast<uint4*>(coefs + (size_t)t * 64);
+    __shared__ uint32_t tile[16 * JT_PITCH];
+    __shared__ __attribute__((aligned(8))) uint8_t Ys[16][JT_PX];
+    __shared__ __attribute__((aligned(8))) uint8_t Cs[2][8][JT_PX / 2];
+    const int tid = threadIdx.x, page = blockIdx.z, mcy = blockIdx.y;
+    const int x0 = blockIdx.x * JT_PX, y0 = mcy * 16;
+    const int rows_valid = min(16, g.h - y0), cols_valid = min(JT_PX, g.w - x0);
+    const long long g0 = (((long long)page * g.h + y0) * g.w + x0) * 3;
+    fill_rows(tile, JT_PITCH, (cols_valid * 3 + 3 + 3) / 4, rgb, g0, (long long)g.w * 3, rows_valid, 0, rows_valid, (long long)n * g.h * g.w * 3,
+              WordIdentity());
+    __syncthreads();
+    const uintptr_t ibase = reinterpret_cast<uintptr_t>(rgb);
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+    const int m0 = (int)((ibase + (unsigned long long)g0) & 3), dm = (g.w * 3) & 3;
+#define JPX(r_, c_) (tb + (r_) * (JT_PITCH * 4) + ((m0 + (r_) * dm) & 3) + (c_) * 3)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {   // luma: rows / columns past the image repeat its last row / column
+        const int r = k, c = tid;
+        const uint8_t* px = JPX(min(r, rows_valid - 1), min(c, cols_valid - 1));
+        Ys[r][c] = (uint8_t)ycc_y(px[0], px[1], px[2]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {    // chroma: rows past the last down-sampled row repeat IT; columns are replicated at full resolution
+        const int qd = tid + 256 * k, yc = qd >> 7, xc = qd & 127;
+        const int ycl = min((y0 >> 1) + yc, g.crows - 1) - (y0 >> 1);
+        const int r0 = 2 * ycl, r1 = min(2 * ycl + 1, rows_valid - 1);
+        const int c0 = min(2 * xc, cols_valid - 1), c1 = min(2 * xc + 1, cols_valid - 1);
+        const uint8_t *p00 = JPX(r0, c0), *p01 = JPX(r0, c1), *p10 = JPX(r1, c0), *p11 = JPX(r1, c1);
+        const int bias = (xc & 1) ? 2 : 1;
+        Cs[0][yc][xc] = (uint8_t)((ycc_cb(p00[0], p00[1], p00[2]) + ycc_cb(p01[0], p01[1], p01[2]) + ycc_cb(p10[0], p10[1], p10[2]) + ycc_cb(p11[0], p11[1], p11[2]) + bias) >> 2);
+        Cs[1][yc][xc] = (uint8_t)((ycc_cr(p00[0], p00[1], p00[2]) + ycc_cr(p01[0], p01[1], p01[2]) + ycc_cr(p10[0], p10[1], p10[2]) + ycc_cr(p11[0], p11[1], p11[2]) + bias) >> 2);
+    }
+#undef JPX
+    __syncthreads();
+    if (tid >= 96) return;
+    const int ml = tid / 6, b = tid - ml * 6, mcx = blockIdx.x * 16 + ml;
+    if (mcx >= g.mx) return;
+    const size_t blk = ((size_t)page * g.mcus + (size_t)mcy * g.mx + mcx) * 6 + b;
+    uint4* dst = reinterpret_cast<uint4*>(coefs + blk * 64);
     int d[64];
     if (b < 4) {
         const int bx = 2 * mcx + (b & 1), by = 2 * mcy + (b >> 1);
@@ -78,33 +114,16 @@ __global__ __launch_bounds__(256) void jpeg_coef_kernel(const uint8_t* rgb, int 
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int y = min(by * 8 + r, g.h - 1);
+            const uint2 v = *reinterpret_cast<const uint2*>(&Ys[(b >> 1) * 8 + r][(2 * ml + (b & 1)) * 8]);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int x = min(bx * 8 + c, g.w - 1);
-                const uint8_t* px = img + ((size_t)y * g.w + x) * 3;
-                d[r * 8 + c] = ycc_y(px[0], px[1], px[2]) - 128;
-            }
+            for (int c = 0; c < 8; ++c) d[r * 8 + c] = (int)(((c < 4 ? v.x : v.y) >> (8 * (c & 3))) & 0xffu) - 128;
         }
     } else {
-        const bool is_cr = b == 5;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int yc = min(mcy * 8 + r, g.crows - 1);   // rows past the last down-sampled row repeat it
-            const int r0 = 2 * yc, r1 = min(2 * yc + 1, g.h - 1);
+            const uint2 v = *reinterpret_cast<const uint2*>(&Cs[b - 4][r][ml * 8]);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int xc = mcx * 8 + c;
-                const int c0 = min(2 * xc, g.w - 1), c1 = min(2 * xc + 1, g.w - 1);  // columns are replicated at full resolution
-                int s = (xc & 1) ? 2 : 1;
-                const uint8_t* p00 = img + ((size_t)r0 * g.w + c0) * 3;
-                const uint8_t* p01 = img + ((size_t)r0 * g.w + c1) * 3;
-                const uint8_t* p10 = img + ((size_t)r1 * g.w + c0) * 3;
-                const uint8_t* p11 = img + ((size_t)r1 * g.w + c1) * 3;
-                if (is_cr) s += ycc_cr(p00[0], p00[1], p00[2]) + ycc_cr(p01[0], p01[1], p01[2]) + ycc_cr(p10[0], p10[1], p10[2]) + ycc_cr(p11[0], p11[1], p11[2]);
-                else s += ycc_cb(p00[0], p00[1], p00[2]) + ycc_cb(p01[0], p01[1], p01[2]) + ycc_cb(p10[0], p10[1], p10[2]) + ycc_cb(p11[0], p11[1], p11[2]);
-                d[r * 8 + c] = (s >> 2) - 128;
-            }
+            for (int c = 0; c < 8; ++c) d[r * 8 + c] = (int)(((c < 4 ? v.x : v.y) >> (8 * (c & 3))) & 0xffu) - 128;
         }
     }
 #pragma unroll
@@ -549,8 +568,7 @@ size_t jpeg_workspace_bytes(int n, int height, int width) {
 hipError_t jpeg_coefficients_launch(const uint8_t* rgb, int n, int height, int width, int quality, int16_t* coefs, hipStream_t st) {
     const Geo g = make_geo(height, width);
     const QTab q = make_qtab(quality);
-    const long long total = (long long)n * g.nblk;
-    hipLaunchKernelGGL(jpeg_coef_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rgb, n, g, q, coefs);
+    hipLaunchKernelGGL(jpeg_coef_kernel, dim3((g.mx + 15) / 16, g.my, n), dim3(256), 0, st, rgb, n, g, q, coefs);
     hipLaunchKernelGGL(jpeg_dummy_kernel, dim3((n * g.mcus + 255) / 256), dim3(256), 0, st, n, g, coefs);
     return hipGetLastError();
 }

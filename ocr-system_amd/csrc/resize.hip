@@ -7,6 +7,7 @@
 // precompute_coeffs / normalize_coeffs_8bpc, and cached on the device per (in, out) size.
 // HBM-bound: 3 B/px read + 3 B/px written per pass.
 #include "resize.h"
+#include "lds_rows.h"
 
 #include <cmath>
 
@@ -102,46 +103,6 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t* in, uint
         else orow[xb] = (uint8_t)packed;
     }
 }
-
-// ---- LDS row tiles with arbitrary byte alignment -------------------------------------------------------------------------
-// Rows of W*C bytes are not 4-byte aligned in general.  fill_rows() copies `nrows` row segments (row r starts at flat byte
-// index g0 + r*row_stride) into LDS with ALIGNED 4-byte global loads: LDS row r (pitch words) holds the aligned words that
-// cover the segment, so the segment's byte 0 sits at LDS byte offset m_r = (address of the segment start) & 3 of its row.
-// All loads of a batch of 8 items per thread are issued before the first LDS write (one memory latency per batch, not one
-// per row).  f() transforms a loaded word (identity, or the contrast blend).
-template <typename F>
-__device__ __forceinline__ void fill_rows(uint32_t* lds, int pitch, int nw, const uint8_t* img, long long g0, long long row_stride, int nrows,
-                                          int rlo, int rhi, long long total, F f) {
-    const uintptr_t ibase = reinterpret_cast<uintptr_t>(img);
-    const int items = nrows * nw;
-    for (int i0 = 0; i0 < items; i0 += 256 * 8) {
-        uint32_t w[8];
-        int dst[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 256 + (int)threadIdx.x;
-            dst[u] = -1;
-            w[u] = 0;
-            if (i < items) {
-                const int r = i / nw, k = i - r * nw;
-                if (r >= rlo && r < rhi) {
-                    const long long g = g0 + (long long)r * row_stride;
-                    const int m = (int)((ibase + (unsigned long long)g) & 3);
-                    const long long a = g - m + 4ll * k;
-                    dst[u] = r * pitch + k;
-                    if (a >= 0 && a + 4 <= total) w[u] = *reinterpret_cast<const uint32_t*>(img + a);
-                    else
-                        for (int b = 0; b < 4; ++b)
-                            if (a + b >= 0 && a + b < total) w[u] |= (uint32_t)img[a + b] << (8 * b);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (dst[u] >= 0) lds[dst[u]] = f(w[u]);
-    }
-}
-struct WordIdentity { __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return w; } };
 
 // Horizontal pass, RGB fast path (<= HK <= HKMAX taps, segment <= HPXMAX input pixels): one workgroup = HR rows x HX output pixels, one
 // output pixel (of all HR rows) per thread.  The thread's tap coefficients are fetched up front into registers, the HR input
