@@ -84,10 +84,15 @@ class OcrPipeline:
         pend = _Pending(b=b, w=w, h=h, counts_h=counts_h, n=n, processed=processed)
         if n == 0:
             return pend
-        mask = torch.arange(boxes.shape[1], device=boxes.device)[None, :] < counts[:, None]
-        quads = boxes[mask].contiguous()
-        page_idx = torch.arange(b, device=boxes.device, dtype=torch.int32)[:, None].expand(b, boxes.shape[1])[mask].contiguous()
-        det_sc = scores[mask]
+        # the valid (page, slot) pairs are known on the host (counts): one small index upload + three gathers, instead of boolean-mask
+        # indexing (each of those runs a nonzero kernel and synchronises to learn its output size)
+        cap = boxes.shape[1]
+        page_h = np.repeat(np.arange(b, dtype=np.int64), counts_h)
+        slot_h = np.arange(n, dtype=np.int64) - np.repeat(np.cumsum(counts_h) - counts_h, counts_h)
+        flat = torch.from_numpy(page_h * cap + slot_h).to(boxes.device, non_blocking=True)
+        quads = boxes.view(-1, 8).index_select(0, flat)
+        det_sc = scores.view(-1).index_select(0, flat)
+        page_idx = torch.from_numpy(page_h.astype(np.int32)).to(boxes.device, non_blocking=True)
         crops, widths = self.eng.rec_crop(processed, quads, page_idx)
         idx, prob = self.eng.rec_forward(crops, widths)
         text, length, score = self.eng.ctc_decode(idx, prob)
