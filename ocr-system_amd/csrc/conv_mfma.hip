@@ -35,7 +35,8 @@ namespace {
 template <int KS, int S, int BN, int CK, int TW, int NW = 4, int DB = 0, int MT = 2>
 struct Cfg {
     static constexpr int NTHR = NW * 64;
-    static constexpr bool DMA = (DB == 3);          // operands arrive by LDS-DMA (global_load_lds) into a 2-deep LDS ring
+    static constexpr bool DMA = (DB == 3 || DB == 4);  // operands arrive by LDS-DMA (global_load_lds) into a 2-deep LDS ring
+    static constexpr bool POOL = (DB == 4);            // ... and the epilogue is the fused 3x3/s2 max pool (its own instantiation)
     static constexpr int TH = NW * MT;              // TW == 32: every wave owns MT pixel rows (MT 32-pixel MFMA column tiles)
     static constexpr int PAD = (KS == 3) ? 1 : 0;
     static constexpr int HH = (TH - 1) * S + KS;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
     // output-tile origin.  OUT_POOL: a tile yields (TH-2)/2 x (TW-2)/2 pooled pixels and needs the conv rows / columns
     // 2*py - 1 .. 2*py + 1 of each: tiles step by TH-2 / TW-2 conv pixels and start one row / column early (overlap = the
     // price of never writing the un-pooled tensor: 14/16 x 30/32 = 82 % of the MFMA work is net)
-    const bool pool = C::DMA && p.out_mode == OUT_POOL;
+    constexpr bool pool = C::POOL;
     const int oyb = pool ? tile_y * (C::TH - 2) - 1 : tile_y * C::TH, oxb = pool ? tile_x * (TW - 2) - 1 : tile_x * TW;
     const int iy0 = oyb * S - C::PAD, ix0 = oxb * S - C::PAD;
 #pragma unroll
@@ -391,8 +392,8 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
         }
         return;
     }
-    if constexpr (C::DMA) {
-        if (pool) {
+    if constexpr (C::POOL) {
+        {
             // fused 3x3 / s2 / p1 max pool over the staged bf16 tile: pooled pixel (pr, pc) of this tile = max over tile rows
             // 2pr .. 2pr+2, columns 2pc .. 2pc+2 that lie inside the conv output (pool padding is -inf: skipped)
             constexpr int PH = (C::TH - 2) / 2, PW = (TW - 2) / 2;
@@ -563,7 +564,8 @@ hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t strea
             p.tiles_x = ceil_div((p.Wo - 1) / 2 + 1, 15);
         }
         if (p.zeros == nullptr) return hipErrorInvalidValue;
-        if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16) return launch_t<3, 1, 64, 16, 32, 4, 3, 4>(p, stream);
+        if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16)
+            return p.out_mode == OUT_POOL ? launch_t<3, 1, 64, 16, 32, 4, 4, 4>(p, stream) : launch_t<3, 1, 64, 16, 32, 4, 3, 4>(p, stream);
         return hipErrorInvalidValue;
     }
     DISPATCH(3, 1, 32, 32) DISPATCH(3, 1, 64, 32) DISPATCH(3, 1, 128, 32) DISPATCH(3, 1, 64, 16)
