@@ -325,6 +325,65 @@ def make_rec_weights(seed: int = 4321, num_classes: int = 6625, scale: float = 0
 
 
 # --------------------------------------------------------------------------------------
+# Recognition, second family: SVTR-Tiny (single visual model: patch embedding -> local / global mixing blocks with height
+# merging -> CTC).  BASELINE configs[4] names an SVTR recogniser with a Hindi dictionary; no implementation, weights or
+# dictionary exist offline, so the architecture below is the build's restatement of the published design
+# (Du et al., "SVTR: Scene Text Recognition with a Single Visual Model", tiny configuration, post-norm blocks) on the 32 x 320
+# crops of this pipeline: 8 x 80 tokens -> 4 x 80 -> 2 x 80 -> 80 time steps.  "Parity unpinned".
+# --------------------------------------------------------------------------------------
+SVTR_DIMS, SVTR_DEPTHS, SVTR_HEADS = (64, 128, 256), (3, 6, 3), (2, 4, 8)
+SVTR_LOCAL_BLOCKS = 6            # the first 6 of the 12 blocks mix locally (window 7 x 11 tokens), the rest globally
+SVTR_WINDOW = (7, 11)
+SVTR_OUT = 192                   # channels of the sequence handed to the CTC head
+SVTR_LN_EPS = 1e-6
+
+
+def svtr_block_table() -> List[dict]:
+    """One entry per mixing block: stage, dim, heads, token grid (h, w), local / global."""
+    rows, idx, h = [], 0, REC_H // 4
+    for s, (dim, depth, heads) in enumerate(zip(SVTR_DIMS, SVTR_DEPTHS, SVTR_HEADS)):
+        for _ in range(depth):
+            rows.append(dict(idx=idx, stage=s, dim=dim, heads=heads, h=h, w=REC_W // 4, local=idx < SVTR_LOCAL_BLOCKS))
+            idx += 1
+        h //= 2
+    return rows
+
+
+def make_svtr_weights(seed: int = 2468, num_classes: int = 6625) -> Dict[str, np.ndarray]:
+    """Seeded weights in the LOCW naming: conv / linear weights OHWI `[out, kh, kw, in]` (.w, bf16), biases and LayerNorm
+    gamma / beta fp32 (.b / .g)."""
+    rng = np.random.default_rng(seed)
+    w: Dict[str, np.ndarray] = {}
+
+    def conv(name, cout, k, cin, gain=1.0):
+        w[name + ".w"] = _he(rng, cout, k, cin, gain)
+        w[name + ".b"] = (rng.standard_normal(cout, dtype=np.float32) * np.float32(0.05)).astype(np.float32)
+
+    def ln(name, c):
+        w[name + ".g"] = (1.0 + 0.1 * rng.standard_normal(c)).astype(np.float32)
+        w[name + ".b"] = (0.05 * rng.standard_normal(c)).astype(np.float32)
+
+    conv("svtr.pe1", SVTR_DIMS[0] // 2, 3, 3, gain=1.3)
+    conv("svtr.pe2", SVTR_DIMS[0], 3, SVTR_DIMS[0] // 2, gain=1.3)
+    w["svtr.pos.w"] = bf16_round((0.5 * rng.standard_normal(((REC_H // 4) * (REC_W // 4), SVTR_DIMS[0]))).astype(np.float32))
+    for b in svtr_block_table():
+        p, c = f"svtr.b{b['idx']}", b["dim"]
+        conv(p + ".qkv", 3 * c, 1, c, gain=0.8)
+        conv(p + ".proj", c, 1, c, gain=0.15)   # small residual branches: with untrained weights larger ones wash the token identity out
+        ln(p + ".ln1", c)
+        conv(p + ".fc1", 4 * c, 1, c, gain=1.0)
+        conv(p + ".fc2", c, 1, 4 * c, gain=0.15)
+        ln(p + ".ln2", c)
+    for s in range(2):
+        conv(f"svtr.sub{s}", SVTR_DIMS[s + 1], 3, SVTR_DIMS[s], gain=1.0)
+        ln(f"svtr.sub{s}.ln", SVTR_DIMS[s + 1])
+    conv("svtr.last", SVTR_OUT, 1, SVTR_DIMS[2], gain=1.4)
+    w["svtr.ctc.fc.w"] = bf16_round(rng.standard_normal((num_classes, SVTR_OUT), dtype=np.float32) * np.float32(12.0 / np.sqrt(SVTR_OUT)))
+    w["svtr.ctc.fc.b"] = (rng.standard_normal(num_classes, dtype=np.float32) * np.float32(0.1)).astype(np.float32)
+    return w
+
+
+# --------------------------------------------------------------------------------------
 # "LOCW" weight container
 #   header : b"LOCW", u32 version(1), u32 n_tensors
 #   tensor : u16 name_len, name, u8 dtype(0=f32,1=bf16), u8 ndim, u32 dims[ndim], u64 nbytes,

@@ -41,6 +41,8 @@ def _act(x: torch.Tensor, act: str) -> torch.Tensor:
         return torch.clamp(0.2 * x + 0.5, 0.0, 1.0)
     if act == "sigmoid":
         return torch.sigmoid(x)
+    if act == "gelu":  # exact (erf) GELU, fp32
+        return F.gelu(x)
     assert act == "none", act
     return x
 
@@ -227,6 +229,81 @@ def rec_forward(wd, crops_u8: np.ndarray, mode="bf16", taps=None):
         if taps is not None:
             taps["rec.feat"] = feat.squeeze(2).permute(0, 2, 1).contiguous().numpy()
         return rec_head(wd, feat, mode)
+
+
+# --------------------------------------------------------------------------------------
+# recognition, second family: SVTR-Tiny (arch.svtr_block_table; "parity unpinned": the restatement defines the arithmetic)
+# Stored tensors are bf16; every linear / conv accumulates in fp32 and rounds once after bias (+ residual) (+ activation);
+# attention scores, soft-max and the probability-weighted sum stay fp32 and round once; LayerNorm is fp32 inside, rounds once.
+# --------------------------------------------------------------------------------------
+def _linear(x, wd, name, act="none", residual=None, mode="bf16"):
+    """x [N,T,Cin] -> [N,T,Cout]; weights stored [Cout,1,1,Cin]."""
+    w = torch.from_numpy(np.ascontiguousarray(wd[name + ".w"])).reshape(wd[name + ".w"].shape[0], -1)
+    y = x @ w.t() + _b(wd, name)
+    if residual is not None:
+        y = y + residual
+    return _rb(_act(y, act), mode)
+
+
+def _layernorm(x, wd, name, mode="bf16"):
+    g, b = torch.from_numpy(wd[name + ".g"]), torch.from_numpy(wd[name + ".b"])
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return _rb((x - mu) / torch.sqrt(var + arch.SVTR_LN_EPS) * g + b, mode)
+
+
+def _svtr_mask(h, w):
+    """[T,T] bool: query (qy,qx) may attend key (ky,kx) iff |ky-qy| <= 3 and |kx-qx| <= 5 (7 x 11 window)."""
+    ys, xs = torch.arange(h).repeat_interleave(w), torch.arange(w).repeat(h)
+    return ((ys[:, None] - ys[None, :]).abs() <= arch.SVTR_WINDOW[0] // 2) & ((xs[:, None] - xs[None, :]).abs() <= arch.SVTR_WINDOW[1] // 2)
+
+
+def svtr_backbone(wd, x, mode="bf16", taps=None):
+    """x [N,3,32,320] normalised -> sequence [N,80,192]."""
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t.contiguous().numpy()
+
+    x = conv_bn_act(x, wd, "svtr.pe1", 2, "gelu", mode=mode)
+    x = conv_bn_act(x, wd, "svtr.pe2", 2, "gelu", mode=mode)                 # [N,64,8,80]
+    n, c, h, w = x.shape
+    t = x.permute(0, 2, 3, 1).reshape(n, h * w, c)
+    t = _rb(t + torch.from_numpy(wd["svtr.pos.w"]), mode); tap("svtr.embed", t)
+    stage = 0
+    for b in arch.svtr_block_table():
+        if b["stage"] != stage:                                               # height merging: conv 3x3 stride (2,1) + LayerNorm
+            img = t.reshape(n, h, w, c).permute(0, 3, 1, 2)
+            img = conv_bn_act(img, wd, f"svtr.sub{stage}", (2, 1), "none", mode=mode)
+            n, c, h, w = img.shape
+            t = _layernorm(img.permute(0, 2, 3, 1).reshape(n, h * w, c), wd, f"svtr.sub{stage}.ln", mode); tap(f"svtr.sub{stage}", t)
+            stage = b["stage"]
+        p, heads = f"svtr.b{b['idx']}", b["heads"]
+        hd = c // heads
+        qkv = _linear(t, wd, p + ".qkv", mode=mode).reshape(n, h * w, 3, heads, hd).permute(2, 0, 3, 1, 4)   # [3,N,heads,T,hd]
+        sc = (qkv[0] @ qkv[1].transpose(-1, -2)) * np.float32(hd ** -0.5)
+        if b["local"]:
+            sc = sc.masked_fill(~_svtr_mask(h, w), float("-inf"))
+        att = _rb((torch.softmax(sc, dim=-1) @ qkv[2]).permute(0, 2, 1, 3).reshape(n, h * w, c), mode)
+        t = _layernorm(_linear(att, wd, p + ".proj", residual=t, mode=mode), wd, p + ".ln1", mode)
+        m = _linear(t, wd, p + ".fc1", act="gelu", mode=mode)
+        t = _layernorm(_linear(m, wd, p + ".fc2", residual=t, mode=mode), wd, p + ".ln2", mode); tap(p, t)
+    pooled = _rb(t.reshape(n, h, w, c).mean(dim=1), mode)                     # [N,80,256]: mean over the 2 remaining rows
+    seq = _linear(pooled, wd, "svtr.last", act="hswish", mode=mode); tap("svtr.seq", seq)
+    return seq
+
+
+def svtr_forward(wd, crops_u8: np.ndarray, mode="bf16", taps=None, widths=None):
+    """crops [N,32,320,3] u8 -> (argmax idx [N,80], max prob [N,80] f32, logits, seq)."""
+    with torch.no_grad():
+        x = rec_normalize(crops_u8, mode)
+        if widths is not None:
+            for i, wv in enumerate(widths):
+                x[i, :, :, int(wv):] = 0
+        seq = svtr_backbone(wd, x, mode, taps)
+        logits = seq @ torch.from_numpy(wd["svtr.ctc.fc.w"]).t() + torch.from_numpy(wd["svtr.ctc.fc.b"])
+        mx, idx = logits.max(dim=2)
+        prob = 1.0 / torch.exp(logits - mx.unsqueeze(2)).sum(dim=2)
+        return idx.numpy(), prob.numpy().astype(np.float32), logits.numpy(), seq.numpy()
 
 
 def ctc_greedy(idx: np.ndarray, prob: np.ndarray, charset: List[str]):
