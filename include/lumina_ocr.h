@@ -91,6 +91,14 @@ int lumina_ocr_resize_lanczos(lumina_ocr_t* h, const uint8_t* in_dev, int n, int
 int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, float contrast, float sharpness,
                        uint8_t* tmp_dev, uint8_t* out_dev, void* stream);
 
+/* Second recogniser family (BASELINE configs[4]: SVTR): same slot and the same outputs as lumina_ocr_load_rec_weights /
+ * lumina_ocr_rec_forward (the `rec` model of the engine call, ocr_service_paddleocr_backup.py:232-238, :285), with an SVTR-Tiny
+ * backbone (patch embedding, local / global mixing blocks, CTC head) instead of CRNN.  Blob: LOCW with the `svtr.*` tensors of
+ * lumina_ocr/arch.py make_svtr_weights. */
+int lumina_ocr_load_svtr_weights(lumina_ocr_t* h, const void* blob, size_t nbytes);
+int lumina_ocr_svtr_forward(lumina_ocr_t* h, const uint8_t* crops_dev, const int32_t* widths_dev, int n_crops, int32_t* idx_dev, float* prob_dev,
+                            void* stream);
+
 /* JPEG hand-off of the processed page: replaces image.save(buffer, format='JPEG', quality=q, optimize=True) inside
  * ImagePreprocessor.compress_for_azure (backend/utils/image_preprocessing.py:526-538; the bytes become OCROutput.processed_image_bytes,
  * ocr_service.py:459, saved by backend/utils/file_manager.py:283-287).  Byte-identical to Pillow's output: JFIF 1.01, YCbCr 4:2:0,

@@ -122,6 +122,17 @@ int lumina_ocr_rec_forward(lumina_ocr_t* h, const uint8_t* crops_dev, const int3
     API_TRY return eng_rec_forward(h, crops_dev, widths_dev, n_crops, idx_dev, prob_dev, (hipStream_t)stream); API_CATCH(h)
 }
 
+int lumina_ocr_load_svtr_weights(lumina_ocr_t* h, const void* blob, size_t nbytes) {
+    if (!h || !blob) return locr_fail(h, "load_svtr_weights", "null argument");
+    API_TRY return eng_load_svtr(h, blob, nbytes); API_CATCH(h)
+}
+
+int lumina_ocr_svtr_forward(lumina_ocr_t* h, const uint8_t* crops_dev, const int32_t* widths_dev, int n_crops, int32_t* idx_dev, float* prob_dev,
+                            void* stream) {
+    if (!h || !crops_dev || !idx_dev || !prob_dev) return locr_fail(h, "svtr_forward", "null argument");
+    API_TRY return eng_svtr_forward(h, crops_dev, widths_dev, n_crops, idx_dev, prob_dev, (hipStream_t)stream); API_CATCH(h)
+}
+
 int lumina_ocr_ctc_decode(lumina_ocr_t* h, const int32_t* idx_dev, const float* prob_dev, int n, int32_t* text_dev, int32_t* len_dev,
                           float* score_dev, void* stream) {
     if (!h || !idx_dev || !prob_dev || !text_dev || !len_dev || !score_dev) return locr_fail(h, "ctc_decode", "null argument");

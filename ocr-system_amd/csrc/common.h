@@ -9,7 +9,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_HSIGMOID = 3, ACT_SIGMOID = 4 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_HSIGMOID = 3, ACT_SIGMOID = 4, ACT_GELU = 5 };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 
@@ -28,6 +28,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case ACT_HSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);  // x * relu6(x + 3) * fp32(1/6), no division
         case ACT_HSIGMOID: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
         case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // exact (erf) GELU
         default: return v;
     }
 }

@@ -8,6 +8,7 @@
 #include "common.h"
 #include "conv_mfma.h"
 #include "mbconv.h"
+#include "svtr.h"
 
 struct Tensor4 {
     bf16_t* p = nullptr;
@@ -42,6 +43,19 @@ struct RecBlock {
     SeLayer sel;
 };
 
+// SVTR-Tiny recogniser (arch.svtr_block_table): every linear layer is a 1x1 ConvLayer run in flat-GEMM mode
+struct SvtrBlock { int dim = 0, heads = 0, gh = 0, gw = 0; bool local = false; ConvLayer qkv, proj, fc1, fc2; float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr; };
+struct SvtrModel {
+    bool loaded = false;
+    int num_classes = 0, ctc_ntiles = 0;
+    bf16_t* pe1_wpk = nullptr; float* pe1_bias = nullptr;   // patch embedding conv 1 (3 -> 32, stride 2): stem kernel
+    ConvLayer pe2, sub[2], last;
+    float *sub_g[2] = {nullptr, nullptr}, *sub_b[2] = {nullptr, nullptr};
+    bf16_t* pos = nullptr;
+    std::vector<SvtrBlock> blocks;
+    bf16_t* ctc_wpk = nullptr; float* ctc_bias = nullptr;
+};
+
 struct HostBlobTensor { int dtype; std::vector<int> dims; const uint8_t* data; size_t nbytes; };
 
 struct lumina_ocr {
@@ -59,6 +73,7 @@ struct lumina_ocr {
     ConvLayer rconv2, xproj[2];
     bf16_t* whh[2] = {nullptr, nullptr};
     bf16_t* ctc_wpk = nullptr; float* ctc_bias = nullptr;
+    SvtrModel svtr;
     // ---- workspace ----
     uint8_t* ws = nullptr; size_t ws_cap = 0, ws_off = 0;
     std::vector<void*> owned;  // device allocations freed at destroy
@@ -88,6 +103,8 @@ int eng_load_det(lumina_ocr* eng, const void* blob, size_t n);
 int eng_load_rec(lumina_ocr* eng, const void* blob, size_t n);
 int eng_det_forward(lumina_ocr* eng, const uint8_t* pages, int B, int H, int W, int Hp, int Wp, bf16_t* prob, hipStream_t st);
 int eng_rec_forward(lumina_ocr* eng, const uint8_t* crops, const int* widths, int N, int* idx, float* prob, hipStream_t st);
+int eng_load_svtr(lumina_ocr* eng, const void* blob, size_t n);
+int eng_svtr_forward(lumina_ocr* eng, const uint8_t* crops, const int* widths, int N, int* idx, float* prob, hipStream_t st);
 int eng_ws_reserve(lumina_ocr* eng, size_t bytes);
 void* eng_ws_alloc(lumina_ocr* eng, size_t bytes);
 int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4* y, const Tensor4* res, int res_shift, int out_mode,

@@ -598,3 +598,161 @@ int eng_rec_forward(lumina_ocr* eng, const uint8_t* crops, const int* widths, in
     }
     return 0;
 }
+
+// ------------------------------------------------------------------------------ SVTR-Tiny recogniser
+static float* upload_f32(lumina_ocr* eng, const std::map<std::string, HostBlobTensor>& m, const std::string& name, int n) {
+    auto it = m.find(name);
+    if (it == m.end() || it->second.dtype != 0 || (int)it->second.dims[0] != n) { locr_fail(eng, "missing/ill-shaped f32 tensor", name.c_str()); return nullptr; }
+    return static_cast<float*>(dev_upload(eng, it->second.data, sizeof(float) * n));
+}
+
+int eng_load_svtr(lumina_ocr* eng, const void* blob, size_t n) {
+    std::map<std::string, HostBlobTensor> m;
+    if (!parse_blob(eng, blob, n, &m)) return 1;
+    HIPCHK(hipSetDevice(eng->device));
+    SvtrModel& M = eng->svtr;
+    M = SvtrModel();
+    const int dims[3] = {64, 128, 256}, depths[3] = {3, 6, 3}, heads[3] = {2, 4, 8};
+    {
+        const HostBlobTensor *w, *b;
+        if (!get_wb(eng, m, "svtr.pe1", &w, &b)) return 1;
+        if (w->dims.size() != 4 || w->dims[0] != 32 || w->dims[1] != 3 || w->dims[3] != 3) return locr_fail(eng, "svtr.pe1", "shape");
+        bf16_t packed[2 * 2 * 32 * 8];
+        pack_stem_weights(reinterpret_cast<const bf16_t*>(w->data), 32, packed);
+        M.pe1_wpk = static_cast<bf16_t*>(dev_upload(eng, packed, sizeof(packed)));
+        M.pe1_bias = static_cast<float*>(dev_upload(eng, b->data, 32 * sizeof(float)));
+    }
+    if (!make_conv(eng, m, "svtr.pe2", 3, 2, 32, 64, 32, 64, ACT_GELU, &M.pe2)) return 1;
+    {
+        auto it = m.find("svtr.pos.w");
+        if (it == m.end() || it->second.dtype != 1 || it->second.dims.size() != 2 || it->second.dims[0] != 640 || it->second.dims[1] != 64)
+            return locr_fail(eng, "svtr.pos", "missing/shape");
+        M.pos = static_cast<bf16_t*>(dev_upload(eng, it->second.data, it->second.nbytes));
+    }
+    int idx = 0, gh = 8;
+    for (int s = 0; s < 3; ++s) {
+        const int c = dims[s];
+        for (int d = 0; d < depths[s]; ++d, ++idx) {
+            M.blocks.emplace_back();
+            SvtrBlock& B = M.blocks.back();
+            B.dim = c; B.heads = heads[s]; B.gh = gh; B.gw = 80; B.local = idx < 6;
+            const std::string p = "svtr.b" + std::to_string(idx);
+            if (!make_conv(eng, m, p + ".qkv", 1, 1, c, 3 * c, c, 3 * c, ACT_NONE, &B.qkv)) return 1;
+            if (!make_conv(eng, m, p + ".proj", 1, 1, c, c, c, c, ACT_NONE, &B.proj)) return 1;
+            if (!make_conv(eng, m, p + ".fc1", 1, 1, c, 4 * c, c, 4 * c, ACT_GELU, &B.fc1)) return 1;
+            if (!make_conv(eng, m, p + ".fc2", 1, 1, 4 * c, c, 4 * c, c, ACT_NONE, &B.fc2)) return 1;
+            B.ln1g = upload_f32(eng, m, p + ".ln1.g", c); B.ln1b = upload_f32(eng, m, p + ".ln1.b", c);
+            B.ln2g = upload_f32(eng, m, p + ".ln2.g", c); B.ln2b = upload_f32(eng, m, p + ".ln2.b", c);
+            if (!B.ln1g || !B.ln1b || !B.ln2g || !B.ln2b) return 1;
+        }
+        if (s < 2) {
+            const std::string p = "svtr.sub" + std::to_string(s);
+            if (!make_conv(eng, m, p, 3, 1, c, dims[s + 1], c, dims[s + 1], ACT_NONE, &M.sub[s])) return 1;  // run at stride 1, even rows kept
+            M.sub_g[s] = upload_f32(eng, m, p + ".ln.g", dims[s + 1]); M.sub_b[s] = upload_f32(eng, m, p + ".ln.b", dims[s + 1]);
+            if (!M.sub_g[s] || !M.sub_b[s]) return 1;
+            gh /= 2;
+        }
+    }
+    if (!make_conv(eng, m, "svtr.last", 1, 1, 256, 192, 256, 192, ACT_HSWISH, &M.last)) return 1;
+    {
+        auto w = m.find("svtr.ctc.fc.w"), b = m.find("svtr.ctc.fc.b");
+        if (w == m.end() || b == m.end() || w->second.dims[1] != 192) return locr_fail(eng, "svtr.ctc.fc", "missing/shape");
+        const int C = w->second.dims[0];
+        M.num_classes = C; M.ctc_ntiles = (C + 63) / 64;
+        std::vector<bf16_t> packed(ctc_packed_weight_elems(C, 192));
+        pack_ctc_weights(reinterpret_cast<const bf16_t*>(w->second.data), C, 192, packed.data());
+        std::vector<float> bias((size_t)M.ctc_ntiles * 64, -1.0e30f);
+        memcpy(bias.data(), b->second.data, sizeof(float) * C);
+        M.ctc_wpk = static_cast<bf16_t*>(dev_upload(eng, packed.data(), packed.size() * sizeof(bf16_t)));
+        M.ctc_bias = static_cast<float*>(dev_upload(eng, bias.data(), bias.size() * sizeof(float)));
+        if (!M.ctc_wpk || !M.ctc_bias) return locr_fail(eng, "upload", "svtr ctc");
+    }
+    M.loaded = true;
+    return 0;
+}
+
+static int svtr_forward_sub(lumina_ocr* eng, const uint8_t* crops, const int* widths, int N, int* idx, float* prob, hipStream_t st) {
+    eng->ws_off = 0;
+    const bool dry = (eng->ws == nullptr) || crops == nullptr;
+    SvtrModel& M = eng->svtr;
+    const int T = 80;
+    Tensor4 e1 = ws_tensor(eng, N, 16, 160, 32);
+    if (!dry && e1.p) {
+        StemParams sp{};
+        sp.x = crops; sp.wpk = M.pe1_wpk; sp.bias = M.pe1_bias; sp.y = e1.p; sp.valid_w_per_img = widths;
+        sp.N = N; sp.H = 32; sp.W = 320; sp.valid_h = 32; sp.valid_w = 320; sp.Ho = 16; sp.Wo = 160; sp.Cout_store = 32;
+        sp.act = ACT_GELU;
+        for (int c = 0; c < 3; ++c) { sp.scale[c] = 2.0f / 255.0f; sp.shift[c] = -1.0f; }
+        hipError_t e = stem_conv_launch(sp, st);
+        if (e != hipSuccess) return locr_fail(eng, "svtr.pe1", hipGetErrorString(e));
+    }
+    Tensor4 e2 = ws_tensor(eng, N, 8, 80, 64);
+    RUN(eng_run_conv(eng, M.pe2, e1, &e2, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st));
+    Tensor4 x = ws_tensor(eng, N, 8, 80, 64);
+    LAUNCH("svtr.pos", svtr_add_pos_launch(e2.p, M.pos, x.p, N, 640, 64, st));
+    tap(eng, "svtr.embed", x);
+    int stage_dim = 64;
+    for (size_t bi = 0; bi < M.blocks.size(); ++bi) {
+        SvtrBlock& B = M.blocks[bi];
+        if (B.dim != stage_dim) {   // height merging: 3x3 conv at stride 1, LayerNorm of the even rows
+            const int s = stage_dim == 64 ? 0 : 1;
+            Tensor4 c1 = ws_tensor(eng, N, x.h, x.w, B.dim);
+            RUN(eng_run_conv(eng, M.sub[s], x, &c1, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st));
+            Tensor4 y = ws_tensor(eng, N, x.h / 2, x.w, B.dim);
+            LAUNCH("svtr.sub.ln", svtr_layernorm_launch(c1.p, M.sub_g[s], M.sub_b[s], y.p, N, x.h, x.h / 2, x.w, B.dim, 2, 1e-6f, st));
+            tap(eng, s == 0 ? "svtr.sub0" : "svtr.sub1", y);
+            x = y; stage_dim = B.dim;
+        }
+        const int Tk = x.h * x.w, c = B.dim;
+        Tensor4 qkv = ws_tensor(eng, N, x.h, x.w, 3 * c);
+        RUN(eng_run_conv(eng, B.qkv, x, &qkv, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
+        Tensor4 att = ws_tensor(eng, N, x.h, x.w, c);
+        LAUNCH("svtr.attn", svtr_attention_launch(qkv.p, att.p, N, Tk, B.heads, B.gh, B.gw, B.local ? 1 : 0, st));
+        Tensor4 pr = ws_tensor(eng, N, x.h, x.w, c);
+        RUN(eng_run_conv(eng, B.proj, att, &pr, &x, 0, OUT_NORMAL, 0, 0, 0, true, st));
+        Tensor4 x1 = ws_tensor(eng, N, x.h, x.w, c);
+        LAUNCH("svtr.ln1", svtr_layernorm_launch(pr.p, B.ln1g, B.ln1b, x1.p, N, x.h, x.h, x.w, c, 1, 1e-6f, st));
+        Tensor4 f1 = ws_tensor(eng, N, x.h, x.w, 4 * c);
+        RUN(eng_run_conv(eng, B.fc1, x1, &f1, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
+        Tensor4 f2 = ws_tensor(eng, N, x.h, x.w, c);
+        RUN(eng_run_conv(eng, B.fc2, f1, &f2, &x1, 0, OUT_NORMAL, 0, 0, 0, true, st));
+        Tensor4 x2 = ws_tensor(eng, N, x.h, x.w, c);
+        LAUNCH("svtr.ln2", svtr_layernorm_launch(f2.p, B.ln2g, B.ln2b, x2.p, N, x.h, x.h, x.w, c, 1, 1e-6f, st));
+        tap(eng, ("svtr.b" + std::to_string(bi)).c_str(), x2);
+        x = x2;
+    }
+    Tensor4 pooled = ws_tensor(eng, N, 1, T, 256);
+    LAUNCH("svtr.pool", svtr_rowmean_launch(x.p, pooled.p, N, x.h, x.w, 256, st));
+    Tensor4 seq = ws_tensor(eng, N, 1, T, 192);
+    RUN(eng_run_conv(eng, M.last, pooled, &seq, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
+    tap(eng, "svtr.seq", seq);
+    if (!dry) {
+        CtcFcParams cp{};
+        cp.seq = seq.p; cp.wpk = M.ctc_wpk; cp.bias = M.ctc_bias; cp.out_idx = idx; cp.out_prob = prob;
+        cp.M = N * T; cp.K = 192; cp.C = M.num_classes; cp.ntiles = M.ctc_ntiles;
+        hipError_t e = ctc_fc_argmax_launch(cp, st);
+        if (e != hipSuccess) return locr_fail(eng, "svtr ctc_fc_argmax", hipGetErrorString(e));
+    }
+    return 0;
+}
+
+int eng_svtr_forward(lumina_ocr* eng, const uint8_t* crops, const int* widths, int N, int* idx, float* prob, hipStream_t st) {
+    if (!eng->svtr.loaded) return locr_fail(eng, "svtr_forward", "SVTR weights not loaded");
+    if (N <= 0) return 0;
+    HIPCHK(hipSetDevice(eng->device));
+    int sb = eng->rec_sub_batch / 2;   // ~3 MB of activations per crop
+    if (sb < 1) sb = 1;
+    if (sb > N) sb = N;
+    uint8_t* keep = eng->ws; eng->ws = nullptr;
+    int rc = svtr_forward_sub(eng, nullptr, nullptr, sb, nullptr, nullptr, st);
+    const size_t need = eng->ws_off + 4096;
+    eng->ws = keep;
+    if (rc) return rc;
+    RUN(eng_ws_reserve(eng, need));
+    eng->taps.clear();
+    for (int b0 = 0; b0 < N; b0 += sb) {
+        const int nb = (N - b0) < sb ? (N - b0) : sb;
+        RUN(svtr_forward_sub(eng, crops + (size_t)b0 * 32 * 320 * 3, widths ? widths + b0 : nullptr, nb, idx + (size_t)b0 * 80, prob + (size_t)b0 * 80, st));
+    }
+    return 0;
+}

@@ -1,0 +1,226 @@
+// SVTR-Tiny recogniser glue kernels (the linear layers and convolutions run on conv_mfma.hip / stem_conv.hip):
+// positional-embedding add, LayerNorm (with the row selection of the stride-(2,1) merging conv and the final row pooling), and
+// the mixing blocks' attention core (local 7 x 11 window or global).  Arithmetic definition: oracle/nets.py svtr_backbone —
+// bf16 stored tensors, fp32 inside (scores, soft-max, probability-weighted sum, mean / variance), one rounding per stored tensor.
+// No reference counterpart exists (BASELINE configs[4] names the model; SURVEY.md §0.5: nothing of it ships): parity unpinned.
+#include "svtr.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// y[n, t, c] = bf16(x[n, t, c] + pos[t, c])
+__global__ void svtr_add_pos_kernel(const bf16_t* x, const bf16_t* pos, bf16_t* y, size_t total8, int tc8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 a = reinterpret_cast<const uint4*>(x)[i], b = reinterpret_cast<const uint4*>(pos)[i % tc8];
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = pack_bf16x2(__uint_as_float(aw[j] << 16) + __uint_as_float(bw[j] << 16), __uint_as_float(aw[j] & 0xFFFF0000u) + __uint_as_float(bw[j] & 0xFFFF0000u));
+        reinterpret_cast<uint4*>(y)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// LayerNorm over C, one wave per output token.  Input token of output (n, oy, x) is (n, oy * row_step, x) of an [N, Hin, W, C]
+// tensor (row_step = 2: the stride-(2,1) merging conv was computed at stride 1 and only its even rows are kept).
+template <int CPL>  // channels per lane: C = 64 * CPL
+__global__ __launch_bounds__(256) void svtr_layernorm_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int N, int Hin, int Hout, int W,
+                                                             int row_step, float eps) {
+    constexpr int C = 64 * CPL;
+    const int lane = threadIdx.x & 63;
+    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= (long long)N * Hout * W) return;
+    const int xw = (int)(tok % W);
+    const long long t2 = tok / W;
+    const int oy = (int)(t2 % Hout), n = (int)(t2 / Hout);
+    const bf16_t* src = x + (((size_t)n * Hin + (size_t)oy * row_step) * W + xw) * C + lane * CPL;
+    float v[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) v[j] = bf16_to_f32(src[j]);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) s += v[j];
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { const float d = v[j] - mu; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    bf16_t* dst = y + (size_t)tok * C + lane * CPL;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) dst[j] = f32_to_bf16((v[j] - mu) * rstd * gamma[lane * CPL + j] + beta[lane * CPL + j]);
+}
+
+// y[n, x, c] = bf16(mean over the H rows of x[n, :, x, c])   (H = 2 at the end of the backbone)
+__global__ void svtr_rowmean_kernel(const bf16_t* x, bf16_t* y, int N, int H, int W, int C) {
+    const size_t total = (size_t)N * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t t = i / C;
+        const int xw = (int)(t % W), n = (int)(t / W);
+        float s = 0.f;
+        for (int r = 0; r < H; ++r) s += bf16_to_f32(x[(((size_t)n * H + r) * W + xw) * C + c]);
+        y[i] = f32_to_bf16(s / (float)H);
+    }
+}
+
+// Attention core, head dimension 32.  One workgroup = 64 queries of one (crop, head); the head's K and V ([T][32] bf16 each) are
+// staged in LDS; thread (q, part) walks every 4th key of the query's key set (the 7 x 11 window for local blocks, all T keys
+// otherwise) twice: pass 1 finds the row maximum, pass 2 accumulates exp(s - max) and the weighted V sum; the four parts of a
+// query are combined through LDS.  fp32 throughout, one bf16 rounding of the output.
+constexpr int AT_HD = 32, AT_Q = 64;
+__global__ __launch_bounds__(256) void svtr_attn_kernel(const bf16_t* qkv, bf16_t* out, int T, int heads, int gh, int gw, int local) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sK = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* sV = sK + (size_t)T * AT_HD;
+    float* red = reinterpret_cast<float*>(sV + (size_t)T * AT_HD);   // [4 parts][64 queries][34]
+    const int tid = threadIdx.x, ql = tid & 63, part = tid >> 6;
+    const int n = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * AT_Q;
+    const int C = heads * AT_HD;
+    const bf16_t* base = qkv + (size_t)n * T * 3 * C;
+    // stage K and V of this head: token t -> qkv[t][1][hd][:], qkv[t][2][hd][:]  (4 x 16 B per token each)
+    for (int i = tid; i < T * 4; i += 256) {
+        const int t = i >> 2, s4 = i & 3;
+        reinterpret_cast<uint4*>(sK)[i] = *reinterpret_cast<const uint4*>(base + ((size_t)t * 3 + 1) * C + hd * AT_HD + s4 * 8);
+        reinterpret_cast<uint4*>(sV)[i] = *reinterpret_cast<const uint4*>(base + ((size_t)t * 3 + 2) * C + hd * AT_HD + s4 * 8);
+    }
+    const int qt = min(q0 + ql, T - 1);
+    float q[AT_HD];
+    {
+        const uint4* qp = reinterpret_cast<const uint4*>(base + (size_t)qt * 3 * C + hd * AT_HD);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const uint4 v = qp[s4];
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { q[s4 * 8 + 2 * j] = __uint_as_float(w4[j] << 16); q[s4 * 8 + 2 * j + 1] = __uint_as_float(w4[j] & 0xFFFF0000u); }
+        }
+    }
+    __syncthreads();
+    const float scale = 0.17677669529663687f;  // 32^-0.5
+    const int qy = qt / gw, qx = qt - qy * gw;
+    const int nkeys = local ? 77 : T;
+#define KEY_OF(i_, key_)                                                           \
+    int key_;                                                                     \
+    if (local) {                                                                  \
+        const int wy_ = (i_) / 11, ky_ = qy - 3 + wy_, kx_ = qx - 5 + ((i_) - wy_ * 11); \
+        key_ = (ky_ >= 0 && ky_ < gh && kx_ >= 0 && kx_ < gw) ? ky_ * gw + kx_ : -1; \
+    } else key_ = (i_);
+#define DOT_K(key_, s_)                                                            \
+    float s_ = 0.f;                                                               \
+    {                                                                             \
+        const uint4* kp_ = reinterpret_cast<const uint4*>(sK + (size_t)(key_) * AT_HD); \
+        _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                        \
+            const uint4 v_ = kp_[s4];                                             \
+            const uint32_t w_[4] = {v_.x, v_.y, v_.z, v_.w};                      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                       \
+                s_ = __builtin_fmaf(q[s4 * 8 + 2 * j], __uint_as_float(w_[j] << 16), s_);          \
+                s_ = __builtin_fmaf(q[s4 * 8 + 2 * j + 1], __uint_as_float(w_[j] & 0xFFFF0000u), s_); \
+            }                                                                     \
+        }                                                                         \
+        s_ *= scale;                                                              \
+    }
+    float m = -3.0e38f;
+    for (int i = part; i < nkeys; i += 4) {
+        KEY_OF(i, key)
+        if (key < 0) continue;
+        DOT_K(key, s)
+        m = fmaxf(m, s);
+    }
+    red[(part * 64 + ql) * 34] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[ql * 34], red[(64 + ql) * 34]), fmaxf(red[(128 + ql) * 34], red[(192 + ql) * 34]));
+    __syncthreads();
+    float l = 0.f, o[AT_HD];
+#pragma unroll
+    for (int d = 0; d < AT_HD; ++d) o[d] = 0.f;
+    for (int i = part; i < nkeys; i += 4) {
+        KEY_OF(i, key)
+        if (key < 0) continue;
+        DOT_K(key, s)
+        const float pr = expf(s - m);
+        l += pr;
+        const uint4* vp = reinterpret_cast<const uint4*>(sV + (size_t)key * AT_HD);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const uint4 v = vp[s4];
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[s4 * 8 + 2 * j] = __builtin_fmaf(pr, __uint_as_float(w4[j] << 16), o[s4 * 8 + 2 * j]);
+                o[s4 * 8 + 2 * j + 1] = __builtin_fmaf(pr, __uint_as_float(w4[j] & 0xFFFF0000u), o[s4 * 8 + 2 * j + 1]);
+            }
+        }
+    }
+#undef KEY_OF
+#undef DOT_K
+    float* mine = red + (part * 64 + ql) * 34;
+    mine[0] = l;
+#pragma unroll
+    for (int d = 0; d < AT_HD; ++d) mine[1 + d] = o[d];
+    __syncthreads();
+    if (part == 0 && q0 + ql < T) {   // combine the four partial sums in a fixed order
+        float lt = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) lt += red[(pp * 64 + ql) * 34];
+        const float inv = 1.0f / lt;
+        uint32_t w[16];
+#pragma unroll
+        for (int d = 0; d < AT_HD; d += 2) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) { a += red[(pp * 64 + ql) * 34 + 1 + d]; b += red[(pp * 64 + ql) * 34 + 2 + d]; }
+            w[d >> 1] = pack_bf16x2(a * inv, b * inv);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)n * T + q0 + ql) * C + hd * AT_HD);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) dst[s4] = make_uint4(w[4 * s4], w[4 * s4 + 1], w[4 * s4 + 2], w[4 * s4 + 3]);
+    }
+}
+
+inline int grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g > 256 * 32 ? 256 * 32 : (g ? g : 1));
+}
+
+}  // namespace
+
+hipError_t svtr_add_pos_launch(const bf16_t* x, const bf16_t* pos, bf16_t* y, int N, int T, int C, hipStream_t st) {
+    const size_t total8 = (size_t)N * T * C / 8;
+    hipLaunchKernelGGL(svtr_add_pos_kernel, dim3(grid_for(total8)), dim3(256), 0, st, x, pos, y, total8, T * C / 8);
+    return hipGetLastError();
+}
+
+hipError_t svtr_layernorm_launch(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int N, int Hin, int Hout, int W, int C, int row_step,
+                                 float eps, hipStream_t st) {
+    const long long tokens = (long long)N * Hout * W;
+    const dim3 grid((unsigned)((tokens + 3) / 4));
+    if (C == 64) hipLaunchKernelGGL(svtr_layernorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, N, Hin, Hout, W, row_step, eps);
+    else if (C == 128) hipLaunchKernelGGL(svtr_layernorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, N, Hin, Hout, W, row_step, eps);
+    else if (C == 256) hipLaunchKernelGGL(svtr_layernorm_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, N, Hin, Hout, W, row_step, eps);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t svtr_rowmean_launch(const bf16_t* x, bf16_t* y, int N, int H, int W, int C, hipStream_t st) {
+    hipLaunchKernelGGL(svtr_rowmean_kernel, dim3(grid_for((size_t)N * W * C)), dim3(256), 0, st, x, y, N, H, W, C);
+    return hipGetLastError();
+}
+
+hipError_t svtr_attention_launch(const bf16_t* qkv, bf16_t* out, int N, int T, int heads, int gh, int gw, int local, hipStream_t st) {
+    if (gh * gw != T || N <= 0) return hipErrorInvalidValue;
+    const size_t lds = (size_t)T * AT_HD * 2 * 2 + (size_t)4 * 64 * 34 * sizeof(float);
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(svtr_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(svtr_attn_kernel, dim3((T + AT_Q - 1) / AT_Q, heads, N), dim3(256), lds, st, qkv, out, T, heads, gh, gw, local);
+    return hipGetLastError();
+}

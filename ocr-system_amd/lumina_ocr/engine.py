@@ -67,6 +67,8 @@ def load_library() -> ctypes.CDLL:
         "lumina_ocr_enhance": (i32, [vp, vp, i32, i32, i32, f32, f32, vp, vp, vp]),
         "lumina_ocr_jpeg_encode": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
         "lumina_ocr_jpeg_coefficients": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+        "lumina_ocr_load_svtr_weights": (i32, [vp, vp, sz]),
+        "lumina_ocr_svtr_forward": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     }
     missing = []
     for name, (res, args) in sig.items():
@@ -88,6 +90,7 @@ EXPORTED_SYMBOLS = [
     "lumina_ocr_det_forward", "lumina_ocr_det_postprocess", "lumina_ocr_rec_crop", "lumina_ocr_rec_forward",
     "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing", "lumina_ocr_conv_timing_detail",
     "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients",
+    "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward",
 ]
 
 
@@ -179,6 +182,13 @@ class Engine:
         self.num_classes = self.lib.lumina_ocr_num_classes(self._h)
         self.rec_loaded = True
 
+    def load_svtr(self, weights):
+        """SVTR-Tiny recogniser weights (arch.make_svtr_weights or a LOCW blob with the svtr.* tensors)."""
+        blob = weights if isinstance(weights, (bytes, bytearray)) else arch.write_blob(weights)
+        buf = ctypes.create_string_buffer(bytes(blob), len(blob))
+        self._chk(self.lib.lumina_ocr_load_svtr_weights(self._h, ctypes.cast(buf, ctypes.c_void_p), len(blob)))
+        self.svtr_loaded = True
+
     # -- hot path -------------------------------------------------------------------------
     def normalize(self, img, hp: int, wp: int, scale, shift, nchw: bool = False):
         torch = _torch()
@@ -231,6 +241,16 @@ class Engine:
         prob = torch.empty((n, REC_T), dtype=torch.float32, device=crops.device)
         if n:
             self._chk(self.lib.lumina_ocr_rec_forward(self._h, _ptr(crops), _ptr(widths), n, _ptr(idx), _ptr(prob), self._stream()))
+        return idx, prob
+
+    def svtr_forward(self, crops, widths=None):
+        """Same contract as rec_forward, SVTR-Tiny backbone."""
+        torch = _torch()
+        n = crops.shape[0]
+        idx = torch.empty((n, REC_T), dtype=torch.int32, device=crops.device)
+        prob = torch.empty((n, REC_T), dtype=torch.float32, device=crops.device)
+        if n:
+            self._chk(self.lib.lumina_ocr_svtr_forward(self._h, _ptr(crops), _ptr(widths), n, _ptr(idx), _ptr(prob), self._stream()))
         return idx, prob
 
     def ctc_decode(self, idx, prob):

@@ -46,7 +46,11 @@ class _Pending:
 
 
 class OcrPipeline:
-    def __init__(self, engine: Engine, charset: Optional[List[str]] = None, max_dimension: int = 2000, post: Optional[dict] = None):
+    def __init__(self, engine: Engine, charset: Optional[List[str]] = None, max_dimension: int = 2000, post: Optional[dict] = None,
+                 recognizer: str = "crnn"):
+        """recognizer: "crnn" (CRNN-MobileNetV3 + BiLSTM, engine.load_rec) or "svtr" (SVTR-Tiny, engine.load_svtr)."""
+        assert recognizer in ("crnn", "svtr")
+        self.recognizer = recognizer
         self.eng = engine
         self.charset = charset or arch.ctc_charset(engine.num_classes or 6625)
         self._codepoints = np.array([ord(c) for c in self.charset], dtype="<u4")   # class id -> code point (vectorised decode)
@@ -94,7 +98,7 @@ class OcrPipeline:
         det_sc = scores.view(-1).index_select(0, flat)
         page_idx = torch.from_numpy(page_h.astype(np.int32)).to(boxes.device, non_blocking=True)
         crops, widths = self.eng.rec_crop(processed, quads, page_idx)
-        idx, prob = self.eng.rec_forward(crops, widths)
+        idx, prob = (self.eng.svtr_forward if self.recognizer == "svtr" else self.eng.rec_forward)(crops, widths)
         text, length, score = self.eng.ctc_decode(idx, prob)
         pend.host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True) for t in (text, length, score, quads, det_sc)]
         pend.event = torch.cuda.Event()
