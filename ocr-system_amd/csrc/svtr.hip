@@ -68,25 +68,29 @@ __global__ void svtr_rowmean_kernel(const bf16_t* x, bf16_t* y, int N, int H, in
     }
 }
 
-// Attention core, head dimension 32.  One workgroup = 64 queries of one (crop, head); the head's K and V ([T][32] bf16 each) are
-// staged in LDS; thread (q, part) walks every 4th key of the query's key set (the 7 x 11 window for local blocks, all T keys
-// otherwise) twice: pass 1 finds the row maximum, pass 2 accumulates exp(s - max) and the weighted V sum; the four parts of a
-// query are combined through LDS.  fp32 throughout, one bf16 rounding of the output.
-constexpr int AT_HD = 32, AT_Q = 64;
-__global__ __launch_bounds__(256) void svtr_attn_kernel(const bf16_t* qkv, bf16_t* out, int T, int heads, int gh, int gw, int local) {
+// Attention core, head dimension 32.  One workgroup = 64 queries of one (crop, head); the head's K ([T][32], expanded to fp32 so
+// that the score loop has no unpacking) and V ([T][32] bf16) are staged in LDS; thread (q, part) walks every AT_PARTS-th key of the
+// query's key set (the 7 x 11 window for local blocks, all T keys otherwise) ONCE with an online soft-max (running maximum,
+// rescaled sum and weighted V accumulator); the AT_PARTS partial soft-maxes of a query are merged through LDS in a fixed order.  fp32 throughout,
+// one bf16 rounding of the output.
+constexpr int AT_HD = 32, AT_Q = 64, AT_RED = 36;   // floats per (part, query) in the merge buffer: m, l, o[32] (+pad)
+constexpr int AT_PARTS = 8;                          // threads per query (512-thread workgroups: two waves per SIMD at one workgroup per CU)
+__global__ __launch_bounds__(64 * AT_PARTS) void svtr_attn_kernel(const bf16_t* qkv, bf16_t* out, int T, int heads, int gh, int gw, int local) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* sK = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* sV = sK + (size_t)T * AT_HD;
-    float* red = reinterpret_cast<float*>(sV + (size_t)T * AT_HD);   // [4 parts][64 queries][34]
+    float* sK = reinterpret_cast<float*>(smem);                                  // [T][32] fp32
+    bf16_t* sV = reinterpret_cast<bf16_t*>(smem + (size_t)T * AT_HD * 4);         // [T][32] bf16
+    float* red = reinterpret_cast<float*>(smem);                                 // aliases sK after the key loop
     const int tid = threadIdx.x, ql = tid & 63, part = tid >> 6;
     const int n = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * AT_Q;
     const int C = heads * AT_HD;
     const bf16_t* base = qkv + (size_t)n * T * 3 * C;
-    // stage K and V of this head: token t -> qkv[t][1][hd][:], qkv[t][2][hd][:]  (4 x 16 B per token each)
-    for (int i = tid; i < T * 4; i += 256) {
+    for (int i = tid; i < T * 4; i += 64 * AT_PARTS) {   // token t, 8-channel slice s4
         const int t = i >> 2, s4 = i & 3;
-        reinterpret_cast<uint4*>(sK)[i] = *reinterpret_cast<const uint4*>(base + ((size_t)t * 3 + 1) * C + hd * AT_HD + s4 * 8);
+        const uint4 kv = *reinterpret_cast<const uint4*>(base + ((size_t)t * 3 + 1) * C + hd * AT_HD + s4 * 8);
         reinterpret_cast<uint4*>(sV)[i] = *reinterpret_cast<const uint4*>(base + ((size_t)t * 3 + 2) * C + hd * AT_HD + s4 * 8);
+        float4* kd = reinterpret_cast<float4*>(sK + (size_t)t * AT_HD + s4 * 8);
+        kd[0] = make_float4(__uint_as_float(kv.x << 16), __uint_as_float(kv.x & 0xFFFF0000u), __uint_as_float(kv.y << 16), __uint_as_float(kv.y & 0xFFFF0000u));
+        kd[1] = make_float4(__uint_as_float(kv.z << 16), __uint_as_float(kv.z & 0xFFFF0000u), __uint_as_float(kv.w << 16), __uint_as_float(kv.w & 0xFFFF0000u));
     }
     const int qt = min(q0 + ql, T - 1);
     float q[AT_HD];
@@ -104,45 +108,33 @@ __global__ __launch_bounds__(256) void svtr_attn_kernel(const bf16_t* qkv, bf16_
     const float scale = 0.17677669529663687f;  // 32^-0.5
     const int qy = qt / gw, qx = qt - qy * gw;
     const int nkeys = local ? 77 : T;
-#define KEY_OF(i_, key_)                                                           \
-    int key_;                                                                     \
-    if (local) {                                                                  \
-        const int wy_ = (i_) / 11, ky_ = qy - 3 + wy_, kx_ = qx - 5 + ((i_) - wy_ * 11); \
-        key_ = (ky_ >= 0 && ky_ < gh && kx_ >= 0 && kx_ < gw) ? ky_ * gw + kx_ : -1; \
-    } else key_ = (i_);
-#define DOT_K(key_, s_)                                                            \
-    float s_ = 0.f;                                                               \
-    {                                                                             \
-        const uint4* kp_ = reinterpret_cast<const uint4*>(sK + (size_t)(key_) * AT_HD); \
-        _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                        \
-            const uint4 v_ = kp_[s4];                                             \
-            const uint32_t w_[4] = {v_.x, v_.y, v_.z, v_.w};                      \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                       \
-                s_ = __builtin_fmaf(q[s4 * 8 + 2 * j], __uint_as_float(w_[j] << 16), s_);          \
-                s_ = __builtin_fmaf(q[s4 * 8 + 2 * j + 1], __uint_as_float(w_[j] & 0xFFFF0000u), s_); \
-            }                                                                     \
-        }                                                                         \
-        s_ *= scale;                                                              \
-    }
-    float m = -3.0e38f;
-    for (int i = part; i < nkeys; i += 4) {
-        KEY_OF(i, key)
-        if (key < 0) continue;
-        DOT_K(key, s)
-        m = fmaxf(m, s);
-    }
-    red[(part * 64 + ql) * 34] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[ql * 34], red[(64 + ql) * 34]), fmaxf(red[(128 + ql) * 34], red[(192 + ql) * 34]));
-    __syncthreads();
-    float l = 0.f, o[AT_HD];
+    float m = -3.0e38f, l = 0.f, o[AT_HD];
 #pragma unroll
     for (int d = 0; d < AT_HD; ++d) o[d] = 0.f;
-    for (int i = part; i < nkeys; i += 4) {
-        KEY_OF(i, key)
+    for (int i = part; i < nkeys; i += AT_PARTS) {
+        int key = i;
+        if (local) {
+            const int wy = i / 11, ky = qy - 3 + wy, kx = qx - 5 + (i - wy * 11);
+            key = (ky >= 0 && ky < gh && kx >= 0 && kx < gw) ? ky * gw + kx : -1;
+        }
         if (key < 0) continue;
-        DOT_K(key, s)
-        const float pr = expf(s - m);
+        const float4* kp = reinterpret_cast<const float4*>(sK + (size_t)key * AT_HD);
+        float sc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 kk = kp[j];
+            sc = __builtin_fmaf(q[4 * j], kk.x, sc); sc = __builtin_fmaf(q[4 * j + 1], kk.y, sc);
+            sc = __builtin_fmaf(q[4 * j + 2], kk.z, sc); sc = __builtin_fmaf(q[4 * j + 3], kk.w, sc);
+        }
+        sc *= scale;
+        if (sc > m) {   // new running maximum: rescale what has been accumulated (exp(-huge) = 0 on the first key)
+            const float corr = expf(m - sc);
+            l *= corr;
+#pragma unroll
+            for (int d = 0; d < AT_HD; ++d) o[d] *= corr;
+            m = sc;
+        }
+        const float pr = expf(sc - m);
         l += pr;
         const uint4* vp = reinterpret_cast<const uint4*>(sV + (size_t)key * AT_HD);
 #pragma unroll
@@ -156,25 +148,27 @@ __global__ __launch_bounds__(256) void svtr_attn_kernel(const bf16_t* qkv, bf16_
             }
         }
     }
-#undef KEY_OF
-#undef DOT_K
-    float* mine = red + (part * 64 + ql) * 34;
-    mine[0] = l;
+    __syncthreads();   // every thread is done with sK: the merge buffer may overwrite it
+    float* mine = red + (part * 64 + ql) * AT_RED;
+    mine[0] = m; mine[1] = l;
 #pragma unroll
-    for (int d = 0; d < AT_HD; ++d) mine[1 + d] = o[d];
+    for (int d = 0; d < AT_HD; ++d) mine[2 + d] = o[d];
     __syncthreads();
-    if (part == 0 && q0 + ql < T) {   // combine the four partial sums in a fixed order
-        float lt = 0.f;
+    if (part == 0 && q0 + ql < T) {   // merge the partial soft-maxes in a fixed order
+        float mt = red[ql * AT_RED];
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) lt += red[(pp * 64 + ql) * 34];
+        for (int pp = 1; pp < AT_PARTS; ++pp) mt = fmaxf(mt, red[(pp * 64 + ql) * AT_RED]);
+        float f[AT_PARTS], lt = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < AT_PARTS; ++pp) { f[pp] = expf(red[(pp * 64 + ql) * AT_RED] - mt); lt += red[(pp * 64 + ql) * AT_RED + 1] * f[pp]; }
         const float inv = 1.0f / lt;
         uint32_t w[16];
 #pragma unroll
         for (int d = 0; d < AT_HD; d += 2) {
-            float a = 0.f, b = 0.f;
+            float a = 0.f, b2 = 0.f;
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) { a += red[(pp * 64 + ql) * 34 + 1 + d]; b += red[(pp * 64 + ql) * 34 + 2 + d]; }
-            w[d >> 1] = pack_bf16x2(a * inv, b * inv);
+            for (int pp = 0; pp < AT_PARTS; ++pp) { a += red[(pp * 64 + ql) * AT_RED + 2 + d] * f[pp]; b2 += red[(pp * 64 + ql) * AT_RED + 3 + d] * f[pp]; }
+            w[d >> 1] = pack_bf16x2(a * inv, b2 * inv);
         }
         uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)n * T + q0 + ql) * C + hd * AT_HD);
 #pragma unroll
@@ -213,7 +207,8 @@ hipError_t svtr_rowmean_launch(const bf16_t* x, bf16_t* y, int N, int H, int W, 
 
 hipError_t svtr_attention_launch(const bf16_t* qkv, bf16_t* out, int N, int T, int heads, int gh, int gw, int local, hipStream_t st) {
     if (gh * gw != T || N <= 0) return hipErrorInvalidValue;
-    const size_t lds = (size_t)T * AT_HD * 2 * 2 + (size_t)4 * 64 * 34 * sizeof(float);
+    size_t lds = (size_t)T * AT_HD * (4 + 2);   // K fp32 + V bf16; the merge buffer aliases K
+    if (lds < (size_t)AT_PARTS * 64 * AT_RED * sizeof(float)) lds = (size_t)AT_PARTS * 64 * AT_RED * sizeof(float);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     static bool attr = false;
     if (!attr) {
@@ -221,6 +216,6 @@ hipError_t svtr_attention_launch(const bf16_t* qkv, bf16_t* out, int N, int T, i
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(svtr_attn_kernel, dim3((T + AT_Q - 1) / AT_Q, heads, N), dim3(256), lds, st, qkv, out, T, heads, gh, gw, local);
+    hipLaunchKernelGGL(svtr_attn_kernel, dim3((T + AT_Q - 1) / AT_Q, heads, N), dim3(64 * AT_PARTS), lds, st, qkv, out, T, heads, gh, gw, local);
     return hipGetLastError();
 }
