@@ -104,6 +104,8 @@ class OCRService:
         self._device = int(os.environ.get("LUMINA_OCR_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self._det_weights = os.environ.get("LUMINA_OCR_DET_WEIGHTS", "")
         self._rec_weights = os.environ.get("LUMINA_OCR_REC_WEIGHTS", "")
+        self._recognizer = os.environ.get("LUMINA_OCR_RECOGNIZER", "crnn")        # "crnn" | "svtr" (BASELINE configs[4] family)
+        self._svtr_weights = os.environ.get("LUMINA_OCR_SVTR_WEIGHTS", "")
         self._weights_kind = "unloaded"
         self._pre = ImagePreprocessor(self.max_dimension)
         self._initialized = True
@@ -129,7 +131,9 @@ class OCRService:
             self._engine = eng
             self._pre._engine = eng
             post = arch.TEXT_PATH_POST if self._weights_kind == "seeded-synthetic" else arch.DEFAULT_POST
-            self._pipeline = OcrPipeline(eng, max_dimension=self.max_dimension, post=post)
+            if self._recognizer == "svtr":
+                eng.load_svtr(Path(self._svtr_weights).read_bytes() if self._svtr_weights else arch.make_svtr_weights())
+            self._pipeline = OcrPipeline(eng, max_dimension=self.max_dimension, post=post, recognizer=self._recognizer)
 
     # ---- single image (:398-475) ----
     def _prepare(self, image: Image.Image) -> np.ndarray:
