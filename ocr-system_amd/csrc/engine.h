@@ -27,6 +27,7 @@ struct ConvLayer {
     // second packing for the 16x32-tile / 4x2-register-tile kernel (3x3, stride 1, >= 64 input channels): picked per launch
     // when the grid is large enough to fill the chip with the bigger tiles
     ConvKernelCfg cfg_big{}; bf16_t* wpk_big = nullptr;
+    bool small_only = false;  // never switch to the 16x32-tile kernel (layers whose maps are only 4-8 rows high)
     bf16_t* fuse_w = nullptr; float fuse_b = 0.f;  // optional fused DBHead tail (see ConvParams)
     float* bias = nullptr;  // device, n_tiles*BN
 };

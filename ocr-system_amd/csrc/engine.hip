@@ -238,10 +238,13 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     }
     static const bool no_big = getenv("LUMINA_CONV_NO_BIG") != nullptr;
     // 16x32 tiles (less LDS and L2 traffic per MFMA) once they still give >= 2 workgroups per CU on all 256 CUs twice over
-    const long long big_blocks = (long long)p.N * ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32) * ((L.cout + L.cfg.bn - 1) / L.cfg.bn);
+    // the variant must not depend on how many images happen to be in this call (the two kernels sum the same products in a
+    // different order): count workgroups for a full sub-batch
+    const long long nb_eff = p.N > eng->det_sub_batch ? p.N : eng->det_sub_batch;
+    const long long big_blocks = nb_eff * ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32) * ((L.cout + L.cfg.bn - 1) / L.cfg.bn);
     static const long long big_min = getenv("LUMINA_CONV_BIG_MIN") ? atoll(getenv("LUMINA_CONV_BIG_MIN")) : 1024;
     if (out_mode == OUT_POOL && (L.wpk_big == nullptr || L.cfg_big.nw != 6)) return locr_fail(eng, "fused max pool needs the LDS-DMA conv kernel", L.name.c_str());
-    const bool use_big = out_mode == OUT_POOL || (!no_big && !flat && L.wpk_big != nullptr && big_blocks >= big_min && L.cin >= 64);
+    const bool use_big = out_mode == OUT_POOL || (!no_big && !flat && !L.small_only && L.wpk_big != nullptr && big_blocks >= big_min && L.cin >= 64);
     ConvKernelCfg cfg = L.cfg;
     if (use_big) { cfg = L.cfg_big; p.wpk = L.wpk_big; }
     static const bool no_pw = getenv("LUMINA_CONV_NO_PW") != nullptr;
@@ -648,6 +651,7 @@ int eng_load_svtr(lumina_ocr* eng, const void* blob, size_t n) {
         if (s < 2) {
             const std::string p = "svtr.sub" + std::to_string(s);
             if (!make_conv(eng, m, p, 3, 1, c, dims[s + 1], c, dims[s + 1], ACT_NONE, &M.sub[s])) return 1;  // run at stride 1, even rows kept
+            M.sub[s].small_only = true;
             M.sub_g[s] = upload_f32(eng, m, p + ".ln.g", dims[s + 1]); M.sub_b[s] = upload_f32(eng, m, p + ".ln.b", dims[s + 1]);
             if (!M.sub_g[s] || !M.sub_b[s]) return 1;
             gh /= 2;

@@ -81,3 +81,32 @@ def test_config4_end_to_end_a4_pages_and_detector_recall(engine, det_weights, re
                 hit += 1
                 break
     assert hit >= 0.75 * len(gt), (hit, len(gt), len(dets[0].quads))
+
+
+def test_config5_svtr_recogniser_batch512_and_devanagari_charset(engine):
+    """BASELINE configs[4] (SVTR recogniser, Hindi dictionary): SVTR-Tiny on 512 crops with a Devanagari class list — batch and
+    sub-batch invariance at size, the oracle on a bounded sample, CTC decode exact on the same ids.  No Hindi dictionary, image or
+    weights ship offline: the class list is the build's own (arch.devanagari_charset), weights are seeded."""
+    from oracle import nets
+    cs = arch.devanagari_charset()
+    weights = arch.make_svtr_weights(num_classes=len(cs))
+    rng = np.random.default_rng(55)
+    base = np.stack([synth.synth_crop(rng)[0] for _ in range(64)])
+    crops = torch.from_numpy(np.concatenate([base] * 8)).cuda()
+    engine.load_svtr(weights)
+    engine.set_option("rec_sub_batch", 300)                                # SVTR sub-batches of 150: 150 + 150 + 150 + 62
+    idx, prob = engine.svtr_forward(crops)
+    engine.set_option("rec_sub_batch", 4096)
+    idx2, prob2 = engine.svtr_forward(crops)
+    torch.cuda.synchronize()
+    assert torch.equal(idx, idx2) and torch.equal(prob, prob2)
+    for r in range(1, 8):
+        assert torch.equal(idx[:64], idx[64 * r:64 * r + 64])
+    assert int(idx.max()) < len(cs)
+    ridx, rprob, _, _ = nets.svtr_forward(weights, base[:6])
+    assert float((idx[:6].cpu().numpy() == ridx).mean()) > 0.9
+    text, length, score = engine.ctc_decode(idx, prob)
+    ref = nets.ctc_greedy(idx[:6].cpu().numpy(), prob[:6].cpu().numpy(), cs)
+    for i in range(6):
+        got = "".join(cs[k] for k in text[i, : int(length[i])].cpu().tolist())
+        assert got == ref[i][0] and np.float32(score[i].item()) == np.float32(ref[i][1])

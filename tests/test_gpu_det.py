@@ -167,3 +167,14 @@ def test_fused_stem_pool_is_bit_identical(engine, det_weights, shape):
     engine.set_option("fuse_pool", 1)
     torch.cuda.synchronize()
     assert torch.equal(a, ref)
+
+
+def test_page_result_is_independent_of_batch_size(engine, det_weights):
+    """The kernel variant of every layer is chosen from the layer geometry and the configured sub-batch, never from the number
+    of pages in the call (different tilings sum the same products in a different order): one page alone == the same page in a batch."""
+    pages = torch.from_numpy(_pages(5, 352, 512, 77)).cuda()
+    engine.load_det(det_weights)
+    batch = engine.det_forward(pages).clone()
+    single = engine.det_forward(pages[2:3]).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(batch[2:3], single)
