@@ -5,6 +5,8 @@
 // No reference counterpart exists (BASELINE configs[4] names the model; SURVEY.md §0.5: nothing of it ships): parity unpinned.
 #include "svtr.h"
 
+#include <cstdlib>
+
 namespace {
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -176,6 +178,119 @@ __global__ __launch_bounds__(64 * AT_PARTS) void svtr_attn_kernel(const bf16_t* 
     }
 }
 
+// Attention core on the matrix cores (flash-attention form, head dimension 32).  One workgroup = MA_W waves x 32 queries of one
+// (crop, head).  K ([T][32] bf16, rows padded to 80 B) and V TRANSPOSED ([32][T] bf16, rows padded) are staged in LDS once.
+// Per 32-key tile a wave computes S^T[key][query] = K Q^T with two 32x32x16 MFMAs (A = K rows from LDS, B = the wave's Q
+// rows, held in registers), masks the keys outside the 7 x 11 window (local blocks), updates the running maximum / sum of its
+// queries (a query's 32 scores live in 16 registers of lane q and 16 of lane q + 32: one cross-half shuffle per reduction),
+// converts P to bf16 (v_permlane32_swap turns the accumulator layout into the 8-consecutive-keys operand layout) and accumulates
+// O^T[d][query] += V^T P^T with two more MFMAs.  Soft-max statistics are fp32; P is rounded to bf16 for the second product.
+constexpr int MA_W = 8, MA_KP = 40;   // waves per workgroup; K row pitch in elements (80 B: conflict-free 16-byte fragment reads)
+__global__ __launch_bounds__(64 * MA_W) void svtr_attn_mfma_kernel(const bf16_t* qkv, bf16_t* out, int T, int heads, int gh, int gw, int local) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int vp = T + 8;                                   // V^T row pitch in elements ((2T + 16) B: odd multiple of 16 B mod 128)
+    bf16_t* sK = reinterpret_cast<bf16_t*>(smem);          // [Tpad][MA_KP]
+    const int Tpad = (T + 31) & ~31;
+    bf16_t* sVt = sK + (size_t)Tpad * MA_KP;               // [32][vp]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * (32 * MA_W) + wave * 32;
+    const int C = heads * AT_HD;
+    const bf16_t* base = qkv + (size_t)n * T * 3 * C;
+    for (int i = tid; i < Tpad * 4; i += 64 * MA_W) {
+        const int t = i >> 2, s4 = i & 3;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (t < T) {
+            kv = *reinterpret_cast<const uint4*>(base + ((size_t)t * 3 + 1) * C + hd * AT_HD + s4 * 8);
+            vv = *reinterpret_cast<const uint4*>(base + ((size_t)t * 3 + 2) * C + hd * AT_HD + s4 * 8);
+        }
+        *reinterpret_cast<uint4*>(sK + (size_t)t * MA_KP + s4 * 8) = kv;
+        const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sVt[(size_t)(s4 * 8 + 2 * j) * vp + t] = (bf16_t)(w4[j] & 0xffffu);
+            sVt[(size_t)(s4 * 8 + 2 * j + 1) * vp + t] = (bf16_t)(w4[j] >> 16);
+        }
+    }
+    // the wave's Q rows as the MFMA B operand: lane (r = query, h) holds d = 16*ks + 8*h .. +7
+    const int qt = min(q0 + r, T - 1);
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(base + (size_t)qt * 3 * C + hd * AT_HD + ks * 16 + h * 8);
+    __syncthreads();
+    if (q0 >= T) return;
+    const float scale = 0.17677669529663687f;
+    const int qy = qt / gw, qx = qt - qy * gw;
+    const int qy_lo = q0 / gw, qy_hi = min(q0 + 31, T - 1) / gw;
+    float m = -3.0e38f, l = 0.f;
+    f32x16_t o;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = 0.f;
+    for (int k0 = 0; k0 < Tpad; k0 += 32) {
+        if (local) {   // whole key tile outside the row band of this query tile: nothing to add
+            const int ky_lo = k0 / gw, ky_hi = min(k0 + 31, T - 1) / gw;
+            if (ky_hi < qy_lo - 3 || ky_lo > qy_hi + 3) continue;
+        }
+        f32x16_t sc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sc[j] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + (size_t)(k0 + r) * MA_KP + ks * 16 + h * 8);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
+        }
+        // lane (query = r): register j is key k0 + (j & 3) + 8 * (j >> 2) + 4 * h
+        float tmax = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int key = k0 + (j & 3) + 8 * (j >> 2) + 4 * h;
+            bool ok = key < T;
+            if (local) {
+                const int ky = key / gw, kx = key - ky * gw;
+                ok = ok && ky >= qy - 3 && ky <= qy + 3 && kx >= qx - 5 && kx <= qx + 5;
+            }
+            sc[j] = ok ? sc[j] * scale : -3.0e38f;
+            tmax = fmaxf(tmax, sc[j]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mn = fmaxf(m, tmax);
+        const float corr = expf(m - mn);     // (both -3e38 before the first valid key: exp(0) = 1 scales zeros)
+        float psum = 0.f;
+        uint32_t pk[8];
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            const float p0 = sc[j] > -1.0e38f ? expf(sc[j] - mn) : 0.f, p1 = sc[j + 1] > -1.0e38f ? expf(sc[j + 1] - mn) : 0.f;
+            psum += p0 + p1;
+            pk[j >> 1] = pack_bf16x2(p0, p1);
+        }
+        psum += __shfl_xor(psum, 32);
+        l = l * corr + psum;
+        m = mn;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j] *= corr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // keys 16*ks .. +15 of the tile: X = registers 8*ks .. +3 (packed pk[4ks], pk[4ks+1]), Y = registers 8*ks+4 .. +7
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * ks], pk[4 * ks + 2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 1], pk[4 * ks + 3], false, false);
+            union { uint32_t u[4]; bf16x8_t v; } pf;
+            pf.u[0] = s0[0]; pf.u[1] = s1[0]; pf.u[2] = s0[1]; pf.u[3] = s1[1];
+            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sVt + (size_t)r * vp + k0 + ks * 16 + h * 8);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o, 0, 0, 0);
+        }
+    }
+    if (q0 + r < T) {   // lane (query = r): register j is d = (j & 3) + 8 * (j >> 2) + 4 * h
+        const float inv = 1.0f / l;
+        bf16_t* dst = out + ((size_t)n * T + q0 + r) * C + hd * AT_HD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w;
+            w.x = pack_bf16x2(o[4 * g] * inv, o[4 * g + 1] * inv);
+            w.y = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            *reinterpret_cast<uint2*>(dst + 8 * g + 4 * h) = w;
+        }
+    }
+}
+
 inline int grid_for(size_t total) {
     size_t g = (total + 255) / 256;
     return (int)(g > 256 * 32 ? 256 * 32 : (g ? g : 1));
@@ -215,6 +330,19 @@ hipError_t svtr_attention_launch(const bf16_t* qkv, bf16_t* out, int N, int T, i
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(svtr_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return e;
         attr = true;
+    }
+    static const bool valu = getenv("LUMINA_SVTR_ATTN_VALU") != nullptr;   // A/B switch: the fp32 VALU kernel
+    if (!valu) {
+        const int Tpad = (T + 31) & ~31;
+        const size_t lds2 = (size_t)Tpad * MA_KP * 2 + (size_t)32 * (T + 8) * 2;
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(svtr_attn_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e != hipSuccess) return e;
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(svtr_attn_mfma_kernel, dim3((T + 32 * MA_W - 1) / (32 * MA_W), heads, N), dim3(64 * MA_W), lds2, st, qkv, out, T, heads, gh, gw, local);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(svtr_attn_kernel, dim3((T + AT_Q - 1) / AT_Q, heads, N), dim3(64 * AT_PARTS), lds, st, qkv, out, T, heads, gh, gw, local);
     return hipGetLastError();
