@@ -240,12 +240,14 @@ __global__ __launch_bounds__(64 * MA_W) void svtr_attn_mfma_kernel(const bf16_t*
         }
         // lane (query = r): register j is key k0 + (j & 3) + 8 * (j >> 2) + 4 * h
         float tmax = -3.0e38f;
+        const int ky0 = k0 / gw, kx0 = k0 - ky0 * gw;   // grid position of the tile's first key (a tile of 32 wraps at most once: gw >= 32)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int key = k0 + (j & 3) + 8 * (j >> 2) + 4 * h;
-            bool ok = key < T;
+            const int off = (j & 3) + 8 * (j >> 2) + 4 * h;
+            bool ok = k0 + off < T;
             if (local) {
-                const int ky = key / gw, kx = key - ky * gw;
+                int kx = kx0 + off, ky = ky0;
+                if (kx >= gw) { kx -= gw; ++ky; }
                 ok = ok && ky >= qy - 3 && ky <= qy + 3 && kx >= qx - 5 && kx <= qx + 5;
             }
             sc[j] = ok ? sc[j] * scale : -3.0e38f;
@@ -321,7 +323,7 @@ hipError_t svtr_rowmean_launch(const bf16_t* x, bf16_t* y, int N, int H, int W, 
 }
 
 hipError_t svtr_attention_launch(const bf16_t* qkv, bf16_t* out, int N, int T, int heads, int gh, int gw, int local, hipStream_t st) {
-    if (gh * gw != T || N <= 0) return hipErrorInvalidValue;
+    if (gh * gw != T || N <= 0 || gw < 32) return hipErrorInvalidValue;
     size_t lds = (size_t)T * AT_HD * (4 + 2);   // K fp32 + V bf16; the merge buffer aliases K
     if (lds < (size_t)AT_PARTS * 64 * AT_RED * sizeof(float)) lds = (size_t)AT_PARTS * 64 * AT_RED * sizeof(float);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
@@ -332,7 +334,7 @@ hipError_t svtr_attention_launch(const bf16_t* qkv, bf16_t* out, int N, int T, i
         attr = true;
     }
     static const bool valu = getenv("LUMINA_SVTR_ATTN_VALU") != nullptr;   // A/B switch: the fp32 VALU kernel
-    if (!valu) {
+    if (!valu && T % 32 == 0) {
         const int Tpad = (T + 31) & ~31;
         const size_t lds2 = (size_t)Tpad * MA_KP * 2 + (size_t)32 * (T + 8) * 2;
         static bool attr2 = false;
