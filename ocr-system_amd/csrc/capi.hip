@@ -57,6 +57,7 @@ int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value) {
     else if (!strcmp(key, "fuse_head")) h->fuse_head = value != 0;
     else if (!strcmp(key, "fuse_mb")) h->fuse_mb = value != 0;
     else if (!strcmp(key, "fuse_pool")) h->fuse_pool = value != 0;
+    else if (!strcmp(key, "fuse_stem")) h->fuse_stem = value != 0;
     else if (!strcmp(key, "post_group")) h->post_group = value > 0 ? value : 1;
     else return locr_fail(h, "set_option: unknown key", key);
     return 0;

@@ -14,12 +14,17 @@ enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_HSIGMOID = 3, A
 __device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 
 // round-to-nearest-even; inputs here are finite (activations), NaN handling not needed on this path
+// fp32 -> bf16, round to nearest even: gfx950's v_cvt_pk_bf16_f32 (one instruction per pair; the integer sequence
+// (u + 0x7fff + lsb) >> 16 it replaces gives the same bits for every non-NaN input)
+typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    return (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    const __bf16 v = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, v);
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    bf16x2_hw_t v;
+    v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -84,6 +84,7 @@ struct lumina_ocr {
     bool keep_taps = false;
     bool fuse_head = true;  // head.convt3 fused into head.convt2's epilogue
     bool fuse_pool = true;  // stem.conv3's epilogue does the 3x3/s2 max pool
+    bool fuse_stem = true;  // stem.conv1 + stem.conv2 in one kernel (the first 32-channel tensor stays in LDS)
     bool fuse_mb = true;    // recogniser blocks: expand + depthwise in one kernel (the expanded tensor stays in LDS)
     // per-kernel event timing (bench roofline): accumulated conv-kernel time of the last det forward
     bool time_convs = false;

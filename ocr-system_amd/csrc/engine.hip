@@ -275,20 +275,26 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
     eng->ws_off = 0;
     const bool dry = (eng->ws == nullptr) || pages == nullptr;
     auto& D = eng->det;
-    Tensor4 t1 = ws_tensor(eng, B, Hp / 2, Wp / 2, 32);
-    if (!dry && t1.p) {
+    // stem.conv1 + stem.conv2 fused (the first half-resolution tensor stays in LDS) unless it is wanted as a tap
+    ConvLayer& c2 = D["stem.conv2"];
+    const bool fuse_stem = eng->fuse_stem && !eng->keep_taps && c2.cfg.bn == 32 && c2.cfg.ck == 16 && c2.act == ACT_RELU;
+    Tensor4 t1{};
+    if (!fuse_stem || dry) t1 = ws_tensor(eng, B, Hp / 2, Wp / 2, 32);
+    Tensor4 t2 = ws_tensor(eng, B, Hp / 2, Wp / 2, 32);
+    if (!dry && t2.p && (fuse_stem || t1.p)) {
         StemParams sp{};
-        sp.x = pages; sp.wpk = eng->stem_wpk; sp.bias = eng->stem_bias; sp.y = t1.p; sp.valid_w_per_img = nullptr;
+        sp.x = pages; sp.wpk = eng->stem_wpk; sp.bias = eng->stem_bias; sp.y = fuse_stem ? t2.p : t1.p; sp.valid_w_per_img = nullptr;
         sp.N = B; sp.H = H; sp.W = W; sp.valid_h = H; sp.valid_w = W; sp.Ho = Hp / 2; sp.Wo = Wp / 2; sp.Cout_store = 32;
         sp.act = ACT_RELU;
         const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
         for (int c = 0; c < 3; ++c) { sp.scale[c] = 1.0f / (255.0f * stdv[c]); sp.shift[c] = -mean[c] / stdv[c]; }
-        hipError_t e = stem_conv_launch(sp, st);
+        hipError_t e = fuse_stem ? stem12_launch(sp, c2.wpk, c2.bias, st) : stem_conv_launch(sp, st);
         if (e != hipSuccess) return locr_fail(eng, "stem.conv1", hipGetErrorString(e));
     }
-    tap(eng, "stem.conv1", t1);
-    Tensor4 t2 = ws_tensor(eng, B, Hp / 2, Wp / 2, 32);
-    RUN(eng_run_conv(eng, D["stem.conv2"], t1, &t2, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "stem.conv2", t2);
+    if (!fuse_stem) {
+        tap(eng, "stem.conv1", t1);
+        RUN(eng_run_conv(eng, c2, t1, &t2, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "stem.conv2", t2);
+    }
     // stem.conv3 + 3x3/s2 max pool: fused (the 64-channel half-resolution tensor, 93 MB per page, is never written) unless the
     // intermediate is wanted as a tap
     const bool fuse_pool = eng->fuse_pool && !eng->keep_taps;

@@ -140,6 +140,174 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
     }
 }
 
+// ---- stem.conv1 + stem.conv2 fused (DBNet): u8 page -> conv 3x3/s2 (3 -> 32) + ReLU -> conv 3x3/s1 (32 -> 32) + ReLU ----
+// The 32-channel half-resolution tensor between the two (46 MB per A4 page, written and read back) only exists as an LDS tile.
+// One workgroup = 8 x 32 output pixels of conv2:
+//   A  the (21 x 69) x 3 u8 input region is normalised into LDS as bf16 (aligned word loads, requested in one batch);
+//   B  conv1 on the matrix cores for the 10 x 34 pixels conv2 needs (11 column tiles of 32 over the four waves; B operand gathered
+//      from the halo exactly as in stem_conv_kernel), + bias, ReLU, bf16 — pixels outside the half-resolution image become ZERO
+//      (conv2 pads its input, not conv1's) — written to a [pixel][32 ch] LDS tile whose 16-byte slots are XOR-swizzled by
+//      (pixel >> 2) & 3 so that conv2's stride-64-byte fragment reads are conflict free;
+//   C  conv2: 2 chunks of 16 channels x 9 taps (the order of the stand-alone kernel: identical sums), A fragments pre-loaded from
+//      the packed weights in L1/L2 into registers, B fragments from the LDS tile; bias, ReLU, staged 64-byte-per-pixel stores.
+constexpr int F_T1H = TH + 2, F_T1W = TW + 2, F_T1PX = F_T1H * F_T1W;           // 10 x 34 = 340 conv1 pixels
+constexpr int F_HH = 2 * (F_T1H - 1) + 3, F_HW = 2 * (F_T1W - 1) + 3;           // 21 x 69 input pixels
+constexpr int F_ROW = F_HW * 3 + 1;                                             // bf16 elements per halo row
+constexpr int F_HALO_BYTES = F_HH * F_ROW * 2, F_T1_BYTES = ((F_T1PX + 31) / 32) * 32 * 64;
+__global__ __launch_bounds__(256) void stem12_kernel(const StemParams p, const bf16_t* w2pk, const float* bias2) {
+    static_assert(256 * STAGE_PITCH <= F_T1_BYTES, "the output stage re-uses the t1 tile");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[F_HALO_BYTES + F_T1_BYTES];
+    bf16_t* halo = reinterpret_cast<bf16_t*>(smem);
+    unsigned char* t1 = smem + F_HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int bid = blockIdx.x;
+    const int n_img = bid / (tiles_x * tiles_y);
+    const int trem = bid - n_img * tiles_x * tiles_y;
+    const int tile_y = trem / tiles_x, tile_x = trem - tile_y * tiles_x;
+    const int vw = p.valid_w, vh = p.valid_h;
+
+    // ---- A: input region -> normalised bf16 halo ----
+    const int y1_0 = tile_y * TH - 1, x1_0 = tile_x * TW - 1;   // conv1-output coordinates of the t1 tile's first pixel
+    const int iy0 = 2 * y1_0 - 1, ix0 = 2 * x1_0 - 1;
+    {
+        constexpr int SEG = F_HW * 3, WPR = (SEG + 3) / 4 + 1, NIT = (F_HH * WPR + 255) / 256;
+        const long long img_off = (long long)n_img * p.H * p.W * 3, all_bytes = (long long)p.N * p.H * p.W * 3;
+        uint32_t word[NIT];
+        long long a0s[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + 256 * u;
+            const int hy = i / WPR, wi = i - hy * WPR, iy = iy0 + hy;
+            word[u] = 0; a0s[u] = 0;
+            if (i < F_HH * WPR && iy >= 0 && iy < vh) {
+                const long long seg0 = img_off + ((long long)iy * p.W + ix0) * 3;
+                const long long a0 = (seg0 & ~3ll) + 4ll * wi;
+                a0s[u] = a0;
+                if (a0 >= 0 && a0 + 4 <= all_bytes) word[u] = *reinterpret_cast<const uint32_t*>(p.x + a0);
+                else for (int b = 0; b < 4; ++b) if (a0 + b >= 0 && a0 + b < all_bytes) word[u] |= (uint32_t)p.x[a0 + b] << (8 * b);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + 256 * u;
+            if (i >= F_HH * WPR) break;
+            const int hy = i / WPR, wi = i - hy * WPR, iy = iy0 + hy;
+            if (iy < 0 || iy >= vh) {
+                for (int b = 0; b < 4; ++b) { const int e = wi * 4 + b; if (e < SEG) halo[hy * F_ROW + e] = 0; }
+                continue;
+            }
+            const long long seg0 = img_off + ((long long)iy * p.W + ix0) * 3;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long long e = a0s[u] + b - seg0;
+                if (e < 0 || e >= SEG) continue;
+                const int hx = (int)e / 3, c = (int)e - hx * 3, ix = ix0 + hx;
+                float v = 0.f;
+                if (ix >= 0 && ix < vw) { v = (float)((word[u] >> (8 * b)) & 0xffu) * p.scale[c]; v = v + p.shift[c]; }
+                halo[hy * F_ROW + (int)e] = f32_to_bf16(v);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- B: conv1 (3 -> 32, stride 2) for the 340 pixels of the t1 tile ----
+    {
+        bf16x8_t a1[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a1[ks] = *reinterpret_cast<const bf16x8_t*>(p.wpk + ((ks * 2 + h) * 32 + r) * 8);
+        float4 b1[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b1[g] = *reinterpret_cast<const float4*>(p.bias + 8 * g + 4 * h);
+        for (int tile = wave; tile * 32 < F_T1PX; tile += 4) {
+            const int pidx = tile * 32 + r;
+            const int pc = min(pidx, F_T1PX - 1);
+            const int py = pc / F_T1W, px = pc - py * F_T1W;
+            f32x16_t acc;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                union { bf16x8_t v; bf16_t s[8]; } b;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = ks * 16 + h * 8 + j;
+                    const int kh = k / 9, kr = k - kh * 9;
+                    b.s[j] = (k < 27) ? halo[(2 * py + kh) * F_ROW + 6 * px + kr] : (bf16_t)0;
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], b.v, acc, 0, 0, 0);
+            }
+            const int y1 = y1_0 + py, x1 = x1_0 + px;
+            const bool inimg = y1 >= 0 && y1 < p.Ho && x1 >= 0 && x1 < p.Wo;   // outside: conv2's zero padding
+            if (pidx < F_T1PX) {
+                const int swz = (pidx >> 2) & 3;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 o = make_uint2(0, 0);
+                    if (inimg) {
+                        o.x = pack_bf16x2(apply_act(acc[4 * g + 0] + b1[g].x, p.act), apply_act(acc[4 * g + 1] + b1[g].y, p.act));
+                        o.y = pack_bf16x2(apply_act(acc[4 * g + 2] + b1[g].z, p.act), apply_act(acc[4 * g + 3] + b1[g].w, p.act));
+                    }
+                    *reinterpret_cast<uint2*>(t1 + pidx * 64 + ((g ^ swz) * 16) + 8 * h) = o;
+                }
+            }
+        }
+    }
+    // conv2 weight fragments (MFMA A operand) of one 16-channel chunk at a time, from L2 (18 KB shared by every work-group):
+    // holding both chunks through phases A and B costs the registers of two more resident work-groups
+    bf16x8_t w2[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) w2[tap] = *reinterpret_cast<const bf16x8_t*>(w2pk + ((size_t)h * (9 * 32) + tap * 32 + r) * 8);
+    __syncthreads();
+
+    // ---- C: conv2 (32 -> 32), chunk (16 channels) outer, tap inner: the stand-alone kernel's summation order ----
+    f32x16_t acc2[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc2[mt][j] = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int pp = (wave * 2 + mt + tap / 3) * F_T1W + r + tap % 3;
+                const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(t1 + pp * 64 + (((2 * kc + h) ^ ((pp >> 2) & 3)) * 16));
+                acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[tap], bf, acc2[mt], 0, 0, 0);
+            }
+        }
+        if (kc == 0) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) w2[tap] = *reinterpret_cast<const bf16x8_t*>(w2pk + ((size_t)(2 + h) * (9 * 32) + tap * 32 + r) * 8);
+        }
+    }
+    __syncthreads();   // the t1 tile is re-used as the output stage
+
+    // ---- epilogue: bias + ReLU -> bf16 -> staged 64-byte-per-pixel stores ----
+    unsigned char* stage = t1;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int tp = (wave * 2 + mt) * TW + r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias2 + 8 * g + 4 * h);
+            uint2 o;
+            o.x = pack_bf16x2(apply_act(acc2[mt][4 * g + 0] + b4.x, ACT_RELU), apply_act(acc2[mt][4 * g + 1] + b4.y, ACT_RELU));
+            o.y = pack_bf16x2(apply_act(acc2[mt][4 * g + 2] + b4.z, ACT_RELU), apply_act(acc2[mt][4 * g + 3] + b4.w, ACT_RELU));
+            *reinterpret_cast<uint2*>(stage + tp * STAGE_PITCH + (8 * g + 4 * h) * 2) = o;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 256 * 4; i += 256) {
+        const int tp = i >> 2, ch = i & 3;
+        const int ty = tp / TW, tx = tp - ty * TW;
+        const int oy = tile_y * TH + ty, ox = tile_x * TW + tx;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        *reinterpret_cast<uint4*>(p.y + (((size_t)n_img * p.Ho + oy) * p.Wo + ox) * 32 + ch * 8) = *reinterpret_cast<const uint4*>(stage + tp * STAGE_PITCH + ch * 16);
+    }
+}
+
 // standalone normalise: u8 [N,H,W,3] -> bf16 [N,Hp,Wp,4]-free NHWC(3) or NCHW, zero outside (vh, vw)
 __global__ void normalize_kernel(const uint8_t* x, bf16_t* y, int N, int H, int W, int Hp, int Wp, int vh, int vw,
                                  float s0, float s1, float s2, float b0, float b1, float b2, int nchw) {
@@ -181,6 +349,13 @@ void pack_stem_weights(const bf16_t* ohwi, int cout, bf16_t* out /* [2][2][32][8
 hipError_t stem_conv_launch(const StemParams& p, hipStream_t stream) {
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
     hipLaunchKernelGGL(stem_conv_kernel, dim3(p.N * tiles_x * tiles_y), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t stem12_launch(const StemParams& p, const bf16_t* w2pk, const float* bias2, hipStream_t stream) {
+    if (p.valid_w_per_img != nullptr || p.Cout_store != 32) return hipErrorInvalidValue;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    hipLaunchKernelGGL(stem12_kernel, dim3(p.N * tiles_x * tiles_y), dim3(256), 0, stream, p, w2pk, bias2);
     return hipGetLastError();
 }
 

@@ -169,6 +169,23 @@ def test_fused_stem_pool_is_bit_identical(engine, det_weights, shape):
     assert torch.equal(a, ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901), (3, 96, 130), (1, 33, 35)], ids=lambda s: "b%d_%dx%d" % s)
+def test_fused_stem_convs_are_bit_identical(engine, det_weights, shape):
+    """stem.conv1 + stem.conv2 in one kernel (the 32-channel half-resolution tensor only exists as a 10x34-pixel LDS tile per
+    work-group) must reproduce the two-kernel path exactly: same bf16 rounding of the intermediate, same chunk->tap summation
+    order, conv2's zero padding at the map borders, pages whose size is not a multiple of the tile."""
+    b, h, w = shape
+    pages = torch.from_numpy(_pages(b, h, w, 35)).cuda()
+    engine.load_det(det_weights)
+    engine.set_option("fuse_stem", 1)
+    a = engine.det_forward(pages).clone()
+    engine.set_option("fuse_stem", 0)
+    ref = engine.det_forward(pages).clone()
+    engine.set_option("fuse_stem", 1)
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref)
+
+
 def test_page_result_is_independent_of_batch_size(engine, det_weights):
     """The kernel variant of every layer is chosen from the layer geometry and the configured sub-batch, never from the number
     of pages in the call (different tilings sum the same products in a different order): one page alone == the same page in a batch."""
