@@ -144,7 +144,11 @@ def main():
     traffic = None
     try:  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/r01_pmc_hbm.json, 16-page det forward)
         pmc = json.loads((ROOT / "profiles" / "r01_pmc_hbm.json").read_text())
-        traffic = pmc.get("bench_dominant_kernel", {}).get("hbm_bytes_per_launch")
+        want = dom.replace(" ", "")
+        for name, v in pmc.get("all", pmc).items():     # rocprofv3 prints "conv_ring_kernel<1, false>(ConvParams, ...)"
+            flat = name.replace(" ", "").replace(",false>", ">")
+            if want in flat:
+                traffic = v.get("hbm_bytes_per_launch")
     except Exception:
         pass
 
@@ -172,7 +176,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": "mean HBM bytes/launch of this kernel in a 16-page det forward (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm.json); bench launches cover 16-page sub-batches too",
-                         "family": {"kernel": "all conv launches (conv_mfma_kernel instantiations + conv_pw_kernel)", "launches_per_step": len(rows),
+                         "family": {"kernel": "all conv launches (conv_ring_kernel + conv_mfma_kernel instantiations + conv_pw_kernel)", "launches_per_step": len(rows),
                                     "ms_per_step": round(fam_ms, 3), "achieved": round(fam_gf / fam_ms, 2),
                                     "frac": round(fam_gf / fam_ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}},
         }

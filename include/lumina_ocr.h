@@ -39,7 +39,8 @@ int lumina_ocr_create(int device, lumina_ocr_t** out);
 void lumina_ocr_destroy(lumina_ocr_t* h);
 const char* lumina_ocr_last_error(const lumina_ocr_t* h);
 const char* lumina_ocr_version(void);
-/* options: "det_sub_batch", "rec_sub_batch", "keep_taps", "time_convs", "fuse_head" */
+/* options: "det_sub_batch", "rec_sub_batch", "post_group", "keep_taps", "time_convs"; developer A/B switches (results are
+ * bit-identical either way): "fuse_head", "fuse_pool", "fuse_stem", "fuse_mb", "conv_ring", "ring_orient", "conv_big_min" */
 int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value);
 
 /* weights: "LOCW" container (ocr-system_amd/lumina_ocr/arch.py write_blob), host memory.

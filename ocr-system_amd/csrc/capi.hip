@@ -58,6 +58,9 @@ int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value) {
     else if (!strcmp(key, "fuse_mb")) h->fuse_mb = value != 0;
     else if (!strcmp(key, "fuse_pool")) h->fuse_pool = value != 0;
     else if (!strcmp(key, "fuse_stem")) h->fuse_stem = value != 0;
+    else if (!strcmp(key, "conv_ring")) h->conv_ring = value != 0;
+    else if (!strcmp(key, "conv_big_min")) h->conv_big_min = value >= 0 ? value : 1024;
+    else if (!strcmp(key, "ring_orient")) h->ring_orient = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "post_group")) h->post_group = value > 0 ? value : 1;
     else return locr_fail(h, "set_option: unknown key", key);
     return 0;

@@ -53,6 +53,12 @@ bool conv_pick_cfg(int ks, int stride, int cin, int cout_gemm, ConvKernelCfg* cf
 hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t stream);
 const char* conv_kernel_name(const ConvKernelCfg& cfg);
 
+// Persistent LDS-DMA ring kernel (conv_ring.hip) for 3x3 / stride-1 / OUT_NORMAL layers packed for cfg.nw == 6: same tile,
+// same summation order, bit-identical results; orientation -1 = the tile orientation that pads less, 0 / 1 forced.
+bool conv_ring_supported(const ConvKernelCfg& cfg, const ConvParams& p);
+bool conv_ring_transposed(const ConvParams& p, int orientation);
+hipError_t conv_ring_launch(ConvParams p, int orientation, hipStream_t stream);
+
 // Pixel-stationary pointwise kernel (conv_pw.hip) for Cin 64 / 128, all output channels per workgroup; same packed weights
 // (bn 64, ck 32).  Output modes: OUT_NORMAL (optional top-down add) and OUT_CONVT with the fused DBHead tail.
 bool conv_pw_supported(const ConvKernelCfg& cfg, const ConvParams& p);

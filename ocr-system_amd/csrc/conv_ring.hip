@@ -1,0 +1,372 @@
+// Persistent 3x3 / stride-1 implicit-GEMM convolution for gfx950: the LDS-DMA kernel of conv_mfma.hip (16x32-pixel tile x 64
+// output channels, 16-channel chunks, 4 waves, 4x2 MFMA register tile per wave) re-shaped so that its per-tile fixed costs
+// disappear from the critical path.  Serves the backbone / head layers of the detector (the reference has no local
+// convolution code: /root/reference/backend/services/ocr_service.py:213-246 is a remote call; this is the engine slot).
+//
+// What the one-tile-per-workgroup kernel pays per tile (time = 2.7 + 0.63 * chunks chunk-times) is the DMA
+// latency of its first chunk, the bias / address prologue, the staged epilogue with its two barriers, and the drain of its
+// stores — more than half the time of a 64-channel layer.  Here:
+//   * 2 workgroups per CU stay resident and walk a strided list of tiles (each XCD owns a contiguous range of tiles, the
+//     workgroups of an XCD take neighbouring tiles at the same time: halos and weight slabs are shared in that XCD's L2);
+//   * (tile, chunk) pairs form ONE continuous 2-deep LDS ring: the first chunk of tile t+1 is requested at the start of the
+//     last chunk of tile t and lands under its 72 MFMAs;
+//   * the epilogue never touches LDS: bias + residual + ReLU in registers, v_permlane32_swap makes 16-byte pieces, and the
+//     stores of tile t are issued AFTER the DMA of (t+1, chunk 1): they drain under the MFMAs of (t+1, chunk 0) and the
+//     vmcnt(0) at the next chunk boundary finds them done (vector-memory operations retire in issue order on gfx9, so a
+//     store issued before a DMA would hold that DMA's wait: this is what sank the first persistent attempt);
+//   * orientation: the 16-row x 32-lane tile can lie either way on the image (TR: lanes run down the image).  NHWC makes
+//     both equally coalesced (a pixel's 16-channel chunk is one 32-byte piece either way); the launch picks the orientation
+//     that wastes fewer padded pixels (a 63x45 map: 1.44x -> 1.08x).  The summation order (chunk, tap, k) is the same in
+//     both orientations and in conv_mfma.hip's kernels: results are bit-identical.
+#include "conv_mfma.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+constexpr int R_TH = 16, R_TW = 32, R_HH = 18, R_HW = 34, R_BN = 64, R_MT = 4, R_NT = 2;
+constexpr int R_A_ITEMS = R_HH * R_HW * 2;   // 16-byte pieces of one chunk's halo tile, [pixel][2 slices]
+constexpr int R_W_ITEMS = 9 * R_BN * 2;      // ... of one chunk's weight slab, [tap * 64 + n][2 slices]
+constexpr int R_AIT = (R_A_ITEMS + 255) / 256, R_WIT = (R_W_ITEMS + 255) / 256;
+constexpr int R_A_BYTES = R_AIT * 256 * 16;  // padded to whole rounds of 256 pieces: every halo DMA is a full, branch-free instruction
+constexpr int R_W_BYTES = R_W_ITEMS * 16, R_BUF = R_A_BYTES + R_W_BYTES;
+constexpr int R_BIAS_BYTES = 4096;           // the layer's bias vector (<= 512 output channels) + 1 KB of prefetch scratch
+constexpr int R_LDS = 2 * R_BUF + R_BIAS_BYTES;   // 81,920 B: two workgroups per CU fill the 160 KB exactly
+static_assert(2 * R_LDS <= 160 * 1024, "two resident workgroups per CU");
+
+struct RingTile { int n_img, ntile, oyb, oxb; };
+
+__device__ __forceinline__ bf16x8_t ring_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+
+// PROF (developer tool, LUMINA_RING_PROF=1): per-phase core-clock sums of every wave -> prof[0..7] (see conv_ring_launch)
+template <int TR, bool PROF = false>
+__global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, const int total_tiles, const int per_xcd, const int wg_per_xcd,
+                                                           unsigned long long* prof) {
+    long long t_wait = 0, t_bar = 0, t_issue = 0, t_comp = 0, t_epi = 0, t0 = 0, t1 = 0;
+    const long long t_begin = PROF ? clock64() : 0;
+#define RING_T(acc_) if constexpr (PROF) { t1 = clock64(); acc_ += t1 - t0; t0 = t1; }
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+
+    // logical tile axes: y = the 16-row axis, x = the 32-lane axis; image pixel (ly, lx) sits at pixel offset ly * sy + lx * sx
+    const int LH = TR ? p.W : p.H, LW = TR ? p.H : p.W;
+    const int sy = TR ? 1 : p.W, sx = TR ? p.W : 1;
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int nchunks = p.Cin >> 4;
+
+    const int xcd = blockIdx.x & 7;
+    int lid = xcd * per_xcd + (blockIdx.x >> 3);
+    const int lid_end = min((xcd + 1) * per_xcd, total_tiles);
+    if (lid >= lid_end) return;
+
+    auto decode = [&](int id) {
+        RingTile t;
+        t.ntile = id % p.n_tiles;
+        const int mtile = id / p.n_tiles;
+        t.n_img = mtile / tiles_per_img;
+        const int trem = mtile - t.n_img * tiles_per_img;
+        const int ty = trem / p.tiles_x;
+        t.oyb = ty * R_TH; t.oxb = (trem - ty * p.tiles_x) * R_TW;
+        return t;
+    };
+
+    // halo pieces of this thread (the same for every tile) and their global offsets for the tile being requested
+    int a_goff[R_AIT];
+    auto describe = [&](const RingTile& t) {
+#pragma unroll
+        for (int it = 0; it < R_AIT; ++it) {
+            const int i = tid + 256 * it, pi = i >> 1, c = i & 1;
+            const int hy = pi / R_HW, hx = pi - hy * R_HW;
+            const int ly = t.oyb - 1 + hy, lx = t.oxb - 1 + hx;
+            const bool inb = i < R_A_ITEMS && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
+            a_goff[it] = inb ? (ly * sy + lx * sx) * p.Cin + c * 8 : -1;
+            if (PROF && (p.dbg_skip & 8)) a_goff[it] = i * 8;   // timing experiment: a perfectly coalesced halo (wrong values)
+        }
+    };
+    const bf16_t* ximg;
+    const bf16_t* wbase;
+    auto rebase = [&](const RingTile& t) {
+        ximg = p.x + (size_t)t.n_img * p.H * p.W * p.Cin;
+        wbase = p.wpk + (size_t)t.ntile * nchunks * (R_W_ITEMS * 8);
+    };
+
+    // One LDS-DMA wave-instruction (64 x 16 B): piece `it` of the halo / of the weight slab of (tile, chunk) -> ring buffer.
+    // Halo pieces outside the image (and the padding pieces of the last round) read a block of zeros; the source is selected
+    // arithmetically so that the instruction sits in straight-line code and can be scheduled between the MFMAs.
+    auto dma_a = [&](int it, const bf16_t* xa, int tgt) {
+        const int i = tid + 256 * it;
+        const unsigned long long in_addr = (unsigned long long)xa + 2ull * (unsigned)a_goff[it];
+        const unsigned long long addr = a_goff[it] >= 0 ? in_addr : (unsigned long long)p.zeros;
+        if (!(PROF && (p.dbg_skip & 2)))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
+                (__attribute__((address_space(3))) void*)(smem + tgt + (i - lane) * 16), 16, 0, 0);
+    };
+    auto dma_w = [&](int it, const bf16_t* wsrc, int tgt) {
+        const int i = tid + 256 * it;
+        if ((R_W_ITEMS % 256 == 0 || (it + 1) * 256 <= R_W_ITEMS || wave < (R_W_ITEMS % 256) / 64) && !(PROF && (p.dbg_skip & 1)))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 8),
+                (__attribute__((address_space(3))) void*)(smem + R_A_BYTES + tgt + (i - lane) * 16), 16, 0, 0);
+    };
+    static_assert(R_W_ITEMS % 64 == 0, "weight pieces split on wave boundaries");
+    // the k-th of the R_AIT + R_WIT requests of a chunk: halo first (it may come from HBM), weights (L2) after
+    auto dma_k = [&](int k, const bf16_t* xa, const bf16_t* wsrc, int tgt) {
+        if (k < R_AIT) dma_a(k, xa, tgt); else dma_w(k - R_AIT, wsrc, tgt);
+    };
+    constexpr int R_NDMA = R_AIT + R_WIT;
+
+    f32x16_t acc[R_MT][R_NT];
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int aoff = h * 16 + ((wave * R_MT) * R_HW + r) * 32;   // + mt * R_HW * 32 + tap offset
+    const int woff = R_A_BYTES + h * 16 + r * 32;                // + (tap * 64 + nt * 32) * 32
+
+    // fragment reads run one tap ahead of the MFMAs that use them (see conv_mfma.hip)
+    bf16x8_t bfr[2][R_MT], afr[2][R_NT];
+#define RING_FRAGS(boff_, tap_, set_)                                                                              \
+    {                                                                                                              \
+        const int kh_ = (tap_) / 3, kw_ = (tap_) % 3;                                                               \
+        const int toff_ = ((TR ? kw_ : kh_) * R_HW + (TR ? kh_ : kw_)) * 32;                                        \
+        _Pragma("unroll") for (int mt = 0; mt < R_MT; ++mt) bfr[set_][mt] = ring_frag(smem + (boff_) + aoff + mt * (R_HW * 32) + toff_); \
+        _Pragma("unroll") for (int nt = 0; nt < R_NT; ++nt) afr[set_][nt] = ring_frag(smem + (boff_) + woff + ((tap_) * R_BN + nt * 32) * 32); \
+    }
+    // One chunk: 9 taps x 8 MFMAs.  The R_NDMA requests for the NEXT ring slot (xa_n / ws_n -> tgt_) are spread over the
+    // first 7 taps, one or two per tap, each placed behind an MFMA: a wave pays 60-190 cycles of issue time per LDS-DMA
+    // instruction, which the matrix pipe covers when they are apart (issued in one burst at the chunk boundary they cost
+    // 35-45 % of all wave cycles, measured with the PROF build).
+#define RING_COMPUTE(boff_, tgt_, first_)                                                                                \
+    RING_FRAGS(boff_, 0, 0)                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    _Pragma("unroll") for (int st = 0; st < 9; ++st) {                                                             \
+        _Pragma("unroll") for (int mt = 0; mt < R_MT; ++mt)                                                         \
+            _Pragma("unroll") for (int nt = 0; nt < R_NT; ++nt)                                                    \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][nt], bfr[st & 1][mt], ((first_) && st == 0) ? zero16 : acc[mt][nt], 0, 0, 0); \
+        if (st + 1 < 9) RING_FRAGS(boff_, st + 1, (st + 1) & 1)                                                    \
+        int ndma_ = 0;                                                                                             \
+        _Pragma("unroll") for (int k = 0; k < R_NDMA; ++k)                                                         \
+            if (k * 7 / R_NDMA == st) { dma_k(k, xa_n, ws_n, tgt_); ++ndma_; }                                     \
+        _Pragma("unroll") for (int q_ = 0; q_ < R_MT * R_NT; ++q_) {                                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
+            if (q_ < R_MT + R_NT && st + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 \
+            if (q_ >= 2 && q_ < 2 + ndma_) {                                                                       \
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                                 \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                 \
+            }                                                                                                      \
+        }                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }
+
+    // finished tile waiting for its stores: 8 channels (16 B) of one pixel per lane and register
+    uint4 pk[R_MT][R_NT][2];
+    RingTile done{};
+    bool pending = false;
+    auto store_done = [&]() {
+        bf16_t* yimg = p.y + (size_t)done.n_img * p.H * p.W * p.y_cstride + p.y_coff + done.ntile * R_BN + 8 * h;
+        const int ox = done.oxb + r;
+#pragma unroll
+        for (int mt = 0; mt < R_MT; ++mt) {
+            const int oy = done.oyb + wave * R_MT + mt;
+            if (oy >= LH || ox >= LW) continue;
+            bf16_t* ypix = yimg + (oy * sy + ox * sx) * p.y_cstride;
+#pragma unroll
+            for (int nt = 0; nt < R_NT; ++nt)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) *reinterpret_cast<uint4*>(ypix + nt * 32 + 16 * gp) = pk[mt][nt][gp];
+        }
+    };
+
+    // Epilogue of `cur`, one pixel row (mt) at a time so that at most two rows of residual are in registers: the row after the
+    // one being finished is already requested.  Bias comes from LDS (copied once per workgroup): an ordinary global load here
+    // would make hipcc drain the in-flight DMA at its first use.
+    const float* sBias = reinterpret_cast<const float*>(smem + 2 * R_BUF);
+    RingTile cur{};
+    auto epilogue = [&](auto has_res_t) {
+        constexpr bool HAS_RES = decltype(has_res_t)::value;
+        const float* bsrc = sBias + cur.ntile * R_BN + 4 * h;
+        const bf16_t* rimg = HAS_RES ? p.res + (size_t)cur.n_img * p.H * p.W * p.res_cstride + cur.ntile * R_BN + 4 * h : nullptr;
+        const int ox = cur.oxb + r;
+        uint2 rr[2][R_NT][4];
+        auto load_res = [&](int set, int mt) {
+            const int oy = cur.oyb + wave * R_MT + mt;
+            const bf16_t* rpix = rimg + ((oy < LH && ox < LW) ? oy * sy + ox * sx : 0) * p.res_cstride;
+#pragma unroll
+            for (int nt = 0; nt < R_NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rr[set][nt][g] = *reinterpret_cast<const uint2*>(rpix + nt * 32 + 8 * g);
+        };
+        if constexpr (HAS_RES) load_res(0, 0);
+#pragma unroll
+        for (int mt = 0; mt < R_MT; ++mt) {
+            if constexpr (HAS_RES) { if (mt + 1 < R_MT) load_res((mt + 1) & 1, mt + 1); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < R_NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bsrc + nt * 32 + 8 * g);
+                    float v0 = acc[mt][nt][4 * g + 0] + b4.x, v1 = acc[mt][nt][4 * g + 1] + b4.y;
+                    float v2 = acc[mt][nt][4 * g + 2] + b4.z, v3 = acc[mt][nt][4 * g + 3] + b4.w;
+                    if constexpr (HAS_RES) {
+                        const uint2 rv = rr[mt & 1][nt][g];
+                        v0 += __uint_as_float(rv.x << 16); v1 += __uint_as_float(rv.x & 0xFFFF0000u);
+                        v2 += __uint_as_float(rv.y << 16); v3 += __uint_as_float(rv.y & 0xFFFF0000u);
+                    }
+                    if (p.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    acc[mt][nt][4 * g + 0] = v0; acc[mt][nt][4 * g + 1] = v1; acc[mt][nt][4 * g + 2] = v2; acc[mt][nt][4 * g + 3] = v3;
+                }
+            // a lane holds 4 consecutive channels per accumulator quad; v_permlane32_swap trades quad g of the upper half-wave
+            // for quad g+1 of the lower one: every lane then owns 8 consecutive channels of its pixel
+#pragma unroll
+            for (int nt = 0; nt < R_NT; ++nt)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const int g0 = 2 * gp, g1 = 2 * gp + 1;
+                    const uint32_t q0x = pack_bf16x2(acc[mt][nt][4 * g0 + 0], acc[mt][nt][4 * g0 + 1]), q0y = pack_bf16x2(acc[mt][nt][4 * g0 + 2], acc[mt][nt][4 * g0 + 3]);
+                    const uint32_t q1x = pack_bf16x2(acc[mt][nt][4 * g1 + 0], acc[mt][nt][4 * g1 + 1]), q1y = pack_bf16x2(acc[mt][nt][4 * g1 + 2], acc[mt][nt][4 * g1 + 3]);
+                    const auto sx2 = __builtin_amdgcn_permlane32_swap(q0x, q1x, false, false);
+                    const auto sy2 = __builtin_amdgcn_permlane32_swap(q0y, q1y, false, false);
+                    pk[mt][nt][gp] = make_uint4(sx2[0], sy2[0], sx2[1], sy2[1]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // The residual rows of `cur` are pulled towards this XCD's L2 one chunk before the epilogue reads them (they were written
+    // two layers ago and come from HBM otherwise: three exposed ~2.5k-cycle waits per tile).  There is no prefetch instruction
+    // on gfx950: a 4-byte LDS-DMA per 128-byte line into a scratch corner of LDS does it without touching a register.
+    auto prefetch_res = [&]() {
+        const bf16_t* rimg = p.res + (size_t)cur.n_img * p.H * p.W * p.res_cstride + cur.ntile * R_BN;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int oy = cur.oyb + wave * R_MT + 2 * k + h, ox = cur.oxb + r;
+            const bf16_t* src = rimg + ((oy < LH && ox < LW) ? oy * sy + ox * sx : 0) * p.res_cstride;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                (__attribute__((address_space(3))) void*)(smem + 2 * R_BUF + R_BIAS_BYTES / 2 + wave * 256), 4, 0, 0);
+        }
+    };
+    for (int i = tid; i < p.Cout; i += 256) reinterpret_cast<float*>(smem + 2 * R_BUF)[i] = p.bias[i];
+    cur = decode(lid);
+    RingTile nxt = cur;
+    describe(cur); rebase(cur);
+    int boff = 0;
+    const bf16_t* xa_n = ximg;    // source of the ring slot being requested: (tile, chunk) after the one being computed
+    const bf16_t* ws_n = wbase;
+#pragma unroll
+    for (int k = 0; k < R_NDMA; ++k) dma_k(k, xa_n, ws_n, 0);
+    for (;;) {
+        const int next_lid = lid + wg_per_xcd;
+        // ---- chunk 0 of `cur` (peeled: the previous tile's stores go out here, a whole chunk of MFMAs before the next vmcnt(0))
+        if constexpr (PROF) t0 = clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RING_T(t_wait)
+        __syncthreads();
+        RING_T(t_bar)
+        xa_n += 16; ws_n += R_W_ITEMS * 8;     // nchunks >= 2: request chunk 1
+        if (pending) store_done();
+        RING_T(t_issue)
+        RING_COMPUTE(boff, R_BUF - boff, true)    // first tap: C = 0 (the accumulators are not cleared separately)
+        RING_T(t_comp)
+        boff = R_BUF - boff;
+        for (int chunk = 1; chunk < nchunks; ++chunk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RING_T(t_wait)
+            __syncthreads();
+            RING_T(t_bar)
+            if (chunk + 1 < nchunks) {
+                xa_n += 16; ws_n += R_W_ITEMS * 8;
+            } else if (next_lid < lid_end) {   // the ring runs on into the next tile
+                nxt = decode(next_lid);
+                describe(nxt); rebase(nxt);
+                xa_n = ximg; ws_n = wbase;
+            }                                  // (no next tile: the last chunk is requested once more, into the free slot)
+            if (chunk + 1 == nchunks && p.res != nullptr) prefetch_res();
+            RING_T(t_issue)
+            RING_COMPUTE(boff, R_BUF - boff, false)
+            RING_T(t_comp)
+            boff = R_BUF - boff;
+        }
+
+        // ---- epilogue in registers: + bias (+ residual), activation, bf16, 16-byte pieces ----
+        if (p.res != nullptr) epilogue(std::true_type{}); else epilogue(std::false_type{});
+        RING_T(t_epi)
+        done = cur; pending = true;
+        lid = next_lid;
+        if (lid >= lid_end) break;
+        cur = nxt;
+    }
+    store_done();
+    if constexpr (PROF) {
+        if (lane == 0) {
+            const long long all = clock64() - t_begin;
+            atomicAdd(prof + 0, (unsigned long long)t_wait); atomicAdd(prof + 1, (unsigned long long)t_bar);
+            atomicAdd(prof + 2, (unsigned long long)t_issue); atomicAdd(prof + 3, (unsigned long long)t_comp);
+            atomicAdd(prof + 4, (unsigned long long)t_epi); atomicAdd(prof + 5, (unsigned long long)all);
+            atomicAdd(prof + 6, 1ull);
+        }
+    }
+#undef RING_T
+#undef RING_COMPUTE
+#undef RING_FRAGS
+}
+
+}  // namespace
+
+bool conv_ring_supported(const ConvKernelCfg& cfg, const ConvParams& p) {
+    static const bool off = getenv("LUMINA_CONV_NO_RING") != nullptr;
+    if (off) return false;
+    if (!(cfg.nw == 6 && cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16)) return false;
+    if (p.out_mode != OUT_NORMAL || p.pix_limit != 0 || p.gate != nullptr || p.zeros == nullptr) return false;
+    if (p.Cin < 32 || p.Cin % 16 != 0 || p.Cout % 64 != 0 || p.Cout * 4 > R_BIAS_BYTES / 2 || p.Ho != p.H || p.Wo != p.W) return false;
+    if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
+    if (p.res != nullptr && (p.res_shift != 0 || p.res_h != p.H || p.res_w != p.W || p.res_cstride % 4 != 0 || (long long)p.H * p.W * p.res_cstride >= (1ll << 31))) return false;
+    if ((long long)p.H * p.W * (p.Cin > p.y_cstride ? p.Cin : p.y_cstride) >= (1ll << 31)) return false;   // 32-bit per-image offsets
+    if (p.y_cstride % 8 != 0 || p.y_coff % 8 != 0) return false;
+    return true;
+}
+
+// orientation: -1 = whichever pads less (ties: lanes along the image rows), 0 / 1 forced (tests)
+bool conv_ring_transposed(const ConvParams& p, int orientation) {
+    auto padded = [&](int lh, int lw) { return (long long)ceil_div(lh, R_TH) * R_TH * ceil_div(lw, R_TW) * R_TW; };
+    return orientation < 0 ? padded(p.W, p.H) < padded(p.H, p.W) : orientation != 0;
+}
+
+hipError_t conv_ring_launch(ConvParams p, int orientation, hipStream_t stream) {
+    const bool tr = conv_ring_transposed(p, orientation);
+    const int lh = tr ? p.W : p.H, lw = tr ? p.H : p.W;
+    p.tiles_y = ceil_div(lh, R_TH); p.tiles_x = ceil_div(lw, R_TW); p.n_tiles = p.Cout / R_BN;
+    const long long total = (long long)p.N * p.tiles_x * p.tiles_y * p.n_tiles;
+    if (total <= 0 || total >= (1ll << 31)) return hipErrorInvalidValue;
+    const int per_xcd = (int)((total + 7) / 8);
+    const int wg_per_xcd = per_xcd < 64 ? per_xcd : 64;   // 32 CUs per XCD, two resident workgroups each
+    static const bool prof = getenv("LUMINA_RING_PROF") != nullptr;
+    if (prof) {
+        p.dbg_skip = getenv("LUMINA_CONV_DBG") ? atoi(getenv("LUMINA_CONV_DBG")) : 0;   // developer tool: where do the waves' cycles go (synchronises, prints one line per launch)
+        static unsigned long long* dprof = nullptr;
+        if (!dprof && hipMalloc(&dprof, 64) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(dprof, 0, 64, stream);
+        const void* fnp = tr ? reinterpret_cast<const void*>(conv_ring_kernel<1, true>) : reinterpret_cast<const void*>(conv_ring_kernel<0, true>);
+        hipError_t e = hipFuncSetAttribute(fnp, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
+        if (e != hipSuccess) return e;
+        if (tr) hipLaunchKernelGGL((conv_ring_kernel<1, true>), dim3(8 * wg_per_xcd), dim3(256), R_LDS, stream, p, (int)total, per_xcd, wg_per_xcd, dprof);
+        else hipLaunchKernelGGL((conv_ring_kernel<0, true>), dim3(8 * wg_per_xcd), dim3(256), R_LDS, stream, p, (int)total, per_xcd, wg_per_xcd, dprof);
+        unsigned long long hp[8] = {0};
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(hp, dprof, 64, hipMemcpyDeviceToHost);
+        const double w = hp[6] ? (double)hp[6] : 1.0, all = hp[5] ? (double)hp[5] : 1.0;
+        fprintf(stderr, "[ring prof] %dx%d cin %d cout %d tr %d tiles %lld waves %.0f cycles/wave %.0f: dma-wait %.1f%% barrier %.1f%% issue+stores %.1f%% compute %.1f%% epilogue %.1f%%\n",
+                p.H, p.W, p.Cin, p.Cout, (int)tr, total, w, all / w, 100.0 * hp[0] / all, 100.0 * hp[1] / all, 100.0 * hp[2] / all, 100.0 * hp[3] / all, 100.0 * hp[4] / all);
+        return hipGetLastError();
+    }
+    static bool attr_done[2] = {false, false};
+    const void* fn = tr ? reinterpret_cast<const void*>(conv_ring_kernel<1>) : reinterpret_cast<const void*>(conv_ring_kernel<0>);
+    if (!attr_done[tr]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
+        if (e != hipSuccess) return e;
+        attr_done[tr] = true;
+    }
+    unsigned long long* none = nullptr;
+    if (tr) hipLaunchKernelGGL((conv_ring_kernel<1>), dim3(8 * wg_per_xcd), dim3(256), R_LDS, stream, p, (int)total, per_xcd, wg_per_xcd, none);
+    else hipLaunchKernelGGL((conv_ring_kernel<0>), dim3(8 * wg_per_xcd), dim3(256), R_LDS, stream, p, (int)total, per_xcd, wg_per_xcd, none);
+    return hipGetLastError();
+}

@@ -84,6 +84,9 @@ struct lumina_ocr {
     bool keep_taps = false;
     bool fuse_head = true;  // head.convt3 fused into head.convt2's epilogue
     bool fuse_pool = true;  // stem.conv3's epilogue does the 3x3/s2 max pool
+    int conv_big_min = 1024;  // 16x32-tile kernels once a full sub-batch gives at least this many work-groups
+    bool conv_ring = true;  // persistent ring kernel for the 3x3 / stride-1 layers (conv_ring.hip)
+    int ring_orient = -1;   // its tile orientation: -1 auto, 0 / 1 forced (tests)
     bool fuse_stem = true;  // stem.conv1 + stem.conv2 in one kernel (the first 32-channel tensor stays in LDS)
     bool fuse_mb = true;    // recogniser blocks: expand + depthwise in one kernel (the expanded tensor stays in LDS)
     // per-kernel event timing (bench roofline): accumulated conv-kernel time of the last det forward

@@ -242,14 +242,16 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     // different order): count workgroups for a full sub-batch
     const long long nb_eff = p.N > eng->det_sub_batch ? p.N : eng->det_sub_batch;
     const long long big_blocks = nb_eff * ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32) * ((L.cout + L.cfg.bn - 1) / L.cfg.bn);
-    static const long long big_min = getenv("LUMINA_CONV_BIG_MIN") ? atoll(getenv("LUMINA_CONV_BIG_MIN")) : 1024;
+    static const long long big_min_env = getenv("LUMINA_CONV_BIG_MIN") ? atoll(getenv("LUMINA_CONV_BIG_MIN")) : -1;
+    const long long big_min = big_min_env >= 0 ? big_min_env : eng->conv_big_min;
     if (out_mode == OUT_POOL && (L.wpk_big == nullptr || L.cfg_big.nw != 6)) return locr_fail(eng, "fused max pool needs the LDS-DMA conv kernel", L.name.c_str());
     const bool use_big = out_mode == OUT_POOL || (!no_big && !flat && !L.small_only && L.wpk_big != nullptr && big_blocks >= big_min && L.cin >= 64);
     ConvKernelCfg cfg = L.cfg;
     if (use_big) { cfg = L.cfg_big; p.wpk = L.wpk_big; }
     static const bool no_pw = getenv("LUMINA_CONV_NO_PW") != nullptr;
     const bool use_pw = !no_pw && !use_big && conv_pw_supported(cfg, p);
-    hipError_t e = use_pw ? conv_pw_launch(p, st) : conv_launch(cfg, p, st);
+    const bool use_ring = eng->conv_ring && use_big && !use_pw && conv_ring_supported(cfg, p);
+    hipError_t e = use_ring ? conv_ring_launch(p, eng->ring_orient, st) : (use_pw ? conv_pw_launch(p, st) : conv_launch(cfg, p, st));
     if (e != hipSuccess) return locr_fail(eng, L.name.c_str(), hipGetErrorString(e));
     if (eng->time_convs) {
         HIPCHK(hipEventRecord(e1, st));
@@ -260,6 +262,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         eng->conv_bytes.push_back(2.0 * ((double)x.elems() + px * (out_mode == OUT_CONVT && p.fuse_w ? 4.0 : (double)L.cout) * (out_mode == OUT_UPSAMPLE ? (double)(1 << (2 * up_shift)) : (out_mode == OUT_POOL ? 0.25 : 1.0)) + (res ? px * (double)L.cout / (double)(1 << (2 * res_shift)) : 0.0) + (double)L.ks * L.ks * L.cin * L.cout));
         eng->conv_names.push_back(L.name);
         std::string kname = use_pw ? (L.cin == 64 ? "conv_pw_kernel<64>" : "conv_pw_kernel<128>") : conv_kernel_name(cfg);
+        if (use_ring) kname = conv_ring_transposed(p, eng->ring_orient) ? "conv_ring_kernel<1>" : "conv_ring_kernel<0>";
         if (out_mode == OUT_POOL) { const size_t pos = kname.rfind(",3,4>"); if (pos != std::string::npos) kname.replace(pos, 5, ",4,4>"); }  // the fused-pool instantiation
         eng->conv_kernels.push_back(kname);
     }

@@ -186,6 +186,35 @@ def test_fused_stem_convs_are_bit_identical(engine, det_weights, shape):
     assert torch.equal(a, ref)
 
 
+@pytest.mark.parametrize("orient", [-1, 0, 1], ids=["auto", "rows", "transposed"])
+@pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901), (5, 352, 512), (1, 1000, 330)], ids=lambda s: "b%d_%dx%d" % s)
+def test_ring_conv_kernel_is_bit_identical(engine, det_weights, shape, orient):
+    """The persistent LDS-DMA ring kernel (conv_ring.hip: tiles strided over resident work-groups, register epilogue, stores
+    deferred behind the next tile's DMA, either tile orientation) sums the same products in the same order as the
+    one-tile-per-work-group kernel it replaces: the probability maps must be equal bit for bit (residual and plain layers,
+    channel-offset output into the FPN concat buffer, partial tiles, one or many tiles per work-group)."""
+    b, h, w = shape
+    pages = torch.from_numpy(_pages(b, h, w, 41)).cuda()
+    engine.load_det(det_weights)
+    engine.set_option("conv_big_min", 1)      # the 16x32-tile kernels on every layer that has them, however small the page
+    engine.set_option("time_convs", 1)
+    try:
+        engine.set_option("conv_ring", 0)
+        ref = engine.det_forward(pages).clone()
+        engine.set_option("conv_ring", 1)
+        engine.set_option("ring_orient", orient)
+        a = engine.det_forward(pages).clone()
+        torch.cuda.synchronize()
+        names = [k for _, k, *_ in engine.conv_timing_detail()]
+    finally:
+        engine.set_option("ring_orient", -1)
+        engine.set_option("conv_big_min", 1024)
+        engine.set_option("time_convs", 0)
+    torch.cuda.synchronize()
+    assert sum(k.startswith("conv_ring_kernel") for k in names) >= 10, names
+    assert torch.equal(a, ref)
+
+
 def test_page_result_is_independent_of_batch_size(engine, det_weights):
     """The kernel variant of every layer is chosen from the layer geometry and the configured sub-batch, never from the number
     of pages in the call (different tilings sum the same products in a different order): one page alone == the same page in a batch."""
