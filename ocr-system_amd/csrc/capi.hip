@@ -1,4 +1,5 @@
 // extern "C" surface of liblumina_ocr.so (declared in include/lumina_ocr.h). Nothing throws.
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -33,6 +34,8 @@ int lumina_ocr_create(int device, lumina_ocr_t** out) {
         return 2;
     }
     if (hipSetDevice(device) != hipSuccess) { eng->err = "hipSetDevice failed"; *out = eng; return 2; }
+    if (const char* e = getenv("LUMINA_RING_ORIENT")) eng->ring_orient = atoi(e) < 0 ? -1 : (atoi(e) != 0);   // developer A/B (profiler runs)
+    if (getenv("LUMINA_CONV_NO_RING")) eng->conv_ring = false;
     *out = eng;
     return 0;
 }

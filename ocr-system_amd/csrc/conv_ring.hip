@@ -32,7 +32,7 @@ constexpr int R_W_ITEMS = 9 * R_BN * 2;      // ... of one chunk's weight slab, 
 constexpr int R_AIT = (R_A_ITEMS + 255) / 256, R_WIT = (R_W_ITEMS + 255) / 256;
 constexpr int R_A_BYTES = R_AIT * 256 * 16;  // padded to whole rounds of 256 pieces: every halo DMA is a full, branch-free instruction
 constexpr int R_W_BYTES = R_W_ITEMS * 16, R_BUF = R_A_BYTES + R_W_BYTES;
-constexpr int R_BIAS_BYTES = 4096;           // the layer's bias vector (<= 512 output channels) + 1 KB of prefetch scratch
+constexpr int R_BIAS_BYTES = 4096;           // the layer's bias vector (<= 1024 output channels)
 constexpr int R_LDS = 2 * R_BUF + R_BIAS_BYTES;   // 81,920 B: two workgroups per CU fill the 160 KB exactly
 static_assert(2 * R_LDS <= 160 * 1024, "two resident workgroups per CU");
 
@@ -232,19 +232,6 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
         }
     };
 
-    // The residual rows of `cur` are pulled towards this XCD's L2 one chunk before the epilogue reads them (they were written
-    // two layers ago and come from HBM otherwise: three exposed ~2.5k-cycle waits per tile).  There is no prefetch instruction
-    // on gfx950: a 4-byte LDS-DMA per 128-byte line into a scratch corner of LDS does it without touching a register.
-    auto prefetch_res = [&]() {
-        const bf16_t* rimg = p.res + (size_t)cur.n_img * p.H * p.W * p.res_cstride + cur.ntile * R_BN;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int oy = cur.oyb + wave * R_MT + 2 * k + h, ox = cur.oxb + r;
-            const bf16_t* src = rimg + ((oy < LH && ox < LW) ? oy * sy + ox * sx : 0) * p.res_cstride;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                (__attribute__((address_space(3))) void*)(smem + 2 * R_BUF + R_BIAS_BYTES / 2 + wave * 256), 4, 0, 0);
-        }
-    };
     for (int i = tid; i < p.Cout; i += 256) reinterpret_cast<float*>(smem + 2 * R_BUF)[i] = p.bias[i];
     cur = decode(lid);
     RingTile nxt = cur;
@@ -280,7 +267,6 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
                 describe(nxt); rebase(nxt);
                 xa_n = ximg; ws_n = wbase;
             }                                  // (no next tile: the last chunk is requested once more, into the free slot)
-            if (chunk + 1 == nchunks && p.res != nullptr) prefetch_res();
             RING_T(t_issue)
             RING_COMPUTE(boff, R_BUF - boff, false)
             RING_T(t_comp)
@@ -317,7 +303,7 @@ bool conv_ring_supported(const ConvKernelCfg& cfg, const ConvParams& p) {
     if (off) return false;
     if (!(cfg.nw == 6 && cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16)) return false;
     if (p.out_mode != OUT_NORMAL || p.pix_limit != 0 || p.gate != nullptr || p.zeros == nullptr) return false;
-    if (p.Cin < 32 || p.Cin % 16 != 0 || p.Cout % 64 != 0 || p.Cout * 4 > R_BIAS_BYTES / 2 || p.Ho != p.H || p.Wo != p.W) return false;
+    if (p.Cin < 32 || p.Cin % 16 != 0 || p.Cout % 64 != 0 || p.Cout * 4 > R_BIAS_BYTES || p.Ho != p.H || p.Wo != p.W) return false;
     if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
     if (p.res != nullptr && (p.res_shift != 0 || p.res_h != p.H || p.res_w != p.W || p.res_cstride % 4 != 0 || (long long)p.H * p.W * p.res_cstride >= (1ll << 31))) return false;
     if ((long long)p.H * p.W * (p.Cin > p.y_cstride ? p.Cin : p.y_cstride) >= (1ll << 31)) return false;   // 32-bit per-image offsets
@@ -338,10 +324,15 @@ hipError_t conv_ring_launch(ConvParams p, int orientation, hipStream_t stream) {
     const long long total = (long long)p.N * p.tiles_x * p.tiles_y * p.n_tiles;
     if (total <= 0 || total >= (1ll << 31)) return hipErrorInvalidValue;
     const int per_xcd = (int)((total + 7) / 8);
-    const int wg_per_xcd = per_xcd < 64 ? per_xcd : 64;   // 32 CUs per XCD, two resident workgroups each
+    // LUMINA_RING_WGS (developer experiment): fewer resident workgroups per XCD.  32 halves the kernel's HBM reads on the
+    // 1/4-resolution layers (64 concurrent 16x32 tiles x 612 halo lines x 128 B = 5 MB do not fit the XCD's 4 MB L2 and the
+    // four 32-byte chunk passes over a 64-channel NHWC line re-fetch it) but costs more in latency hiding than it saves.
+    static const int wg_cap = getenv("LUMINA_RING_WGS") ? atoi(getenv("LUMINA_RING_WGS")) : 64;
+    const int wg_per_xcd = per_xcd < wg_cap ? per_xcd : wg_cap;   // 32 CUs per XCD, two resident workgroups each
     static const bool prof = getenv("LUMINA_RING_PROF") != nullptr;
-    if (prof) {
-        p.dbg_skip = getenv("LUMINA_CONV_DBG") ? atoi(getenv("LUMINA_CONV_DBG")) : 0;   // developer tool: where do the waves' cycles go (synchronises, prints one line per launch)
+    static const int dbg = getenv("LUMINA_CONV_DBG") ? atoi(getenv("LUMINA_CONV_DBG")) : 0;
+    p.dbg_skip = dbg;
+    if (prof) {   // developer tool: where do the waves' cycles go (synchronises, prints one line per launch)
         static unsigned long long* dprof = nullptr;
         if (!dprof && hipMalloc(&dprof, 64) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(dprof, 0, 64, stream);

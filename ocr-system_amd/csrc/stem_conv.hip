@@ -19,6 +19,89 @@ constexpr int HH = 2 * (TH - 1) + 3, HW = 2 * (TW - 1) + 3;  // 17 x 65
 constexpr int ROW = HW * 3 + 1;                              // bf16 elements per halo row (odd -> fewer conflicts)
 constexpr int STAGE_PITCH = 32 * 2 + 16;
 
+// Normalised bf16 halo of one workgroup: rows iy0 .. iy0 + NHH - 1, pixels ix0 .. ix0 + NHW - 1 of image n_img, 3 channels
+// interleaved, NROW = NHW * 3 + 1 elements per LDS row (element NHW * 3 of every row is a dump slot nobody reads).
+// Aligned 4-byte words of every row segment, all requested before the first is used; addresses are 32-bit offsets from a
+// 4-byte-aligned, workgroup-uniform base inside this image; e0 = position of a word's first byte in its row segment.  The
+// arithmetic per byte is straight-line (masks and selected indices, no branches: a conditional on the value makes hipcc
+// branch around the conversion, ~35 instructions per byte with the old 64-bit offsets against ~9 now).
+template <int NHH, int NHW, int NROW>
+__device__ __forceinline__ void fill_halo_u8(bf16_t* halo, const StemParams& p, int n_img, int iy0, int ix0, int vh, int vw, int tid) {
+    constexpr int SEG = NHW * 3, WPR = (SEG + 3) / 4 + 1, NIT = (NHH * WPR + 255) / 256;
+    static_assert(NROW > SEG, "one dump element per row");
+    const long long img_off = (long long)n_img * p.H * p.W * 3, all_bytes = (long long)p.N * p.H * p.W * 3;
+    const unsigned char* xal = p.x + (img_off & ~3ll);       // p.x is an allocation base (>= 4-byte aligned)
+    const int mis = (int)(img_off & 3);
+    const long long lo64 = -(img_off & ~3ll), hi64 = all_bytes - (img_off & ~3ll);      // valid byte range relative to xal ...
+    const int lo_lim = lo64 < -0x7fffffffll ? -0x7fffffff : (int)lo64, hi_lim = hi64 > 0x7fffffffll ? 0x7fffffff : (int)hi64;   // ... clamped: offsets are 32-bit
+    const float sc0 = p.scale[0], sc1 = p.scale[1], sc2 = p.scale[2], sh0 = p.shift[0], sh1 = p.shift[1], sh2 = p.shift[2];
+    uint32_t word[NIT];
+    int e0s[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int i = tid + 256 * u;
+        const int hy = i / WPR, wi = i - hy * WPR, iy = iy0 + hy;
+        const int q = mis + (iy * p.W + ix0) * 3;            // segment start relative to xal (negative at x = -1, y = 0)
+        const int w0 = (q & ~3) + 4 * wi;                    // this thread's aligned word
+        e0s[u] = w0 - q;
+        // words that start before the tensor hold only pixels left of the page (zeroed below); the one word that may
+        // straddle the tensor's end is patched after the loop
+        const bool ld = i < NHH * WPR && iy >= 0 && iy < vh && w0 >= lo_lim && w0 + 4 <= hi_lim;
+        const uint32_t wv = *reinterpret_cast<const uint32_t*>(xal + (ld ? w0 : 0));   // xal itself is always readable: lo_lim <= 0 < hi_lim
+        word[u] = ld ? wv : 0u;
+    }
+    if (hi_lim & 3) {                                        // tensor size not a multiple of 4: its last, partial word byte by byte
+#pragma unroll 1
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + 256 * u;
+            const int hy = i / WPR, wi = i - hy * WPR, iy = iy0 + hy;
+            const int q = mis + (iy * p.W + ix0) * 3, w0 = (q & ~3) + 4 * wi;
+            if (i < NHH * WPR && iy >= 0 && iy < vh && w0 >= lo_lim && w0 < hi_lim && w0 + 4 > hi_lim) {
+                uint32_t wv = 0;
+                for (int b = 0; b < 4; ++b) if (w0 + b < hi_lim) wv |= (uint32_t)xal[w0 + b] << (8 * b);
+#pragma unroll
+                for (int uu = 0; uu < NIT; ++uu) if (uu == u) word[uu] = wv;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int i = tid + 256 * u;
+        const int hy = min(i / WPR, NHH - 1), iy = iy0 + hy;
+        const bool rowin = iy >= 0 && iy < vh, item = i < NHH * WPR;
+        const int e0 = e0s[u];                                // -3 .. SEG + 3
+        const int hx0 = (e0 + 3) / 3 - 1, c0 = e0 - hx0 * 3;  // pixel and channel of the word's first byte (e0 >= -3)
+        bf16_t* hrow = halo + hy * NROW;
+        // the channels of the four bytes are c0, c0+1, c0+2, c0 (mod 3): rotate the constants once per word
+        float S[4], T[4];
+        S[0] = c0 == 0 ? sc0 : (c0 == 1 ? sc1 : sc2); S[1] = c0 == 0 ? sc1 : (c0 == 1 ? sc2 : sc0); S[2] = c0 == 0 ? sc2 : (c0 == 1 ? sc0 : sc1); S[3] = S[0];
+        T[0] = c0 == 0 ? sh0 : (c0 == 1 ? sh1 : sh2); T[1] = c0 == 0 ? sh1 : (c0 == 1 ? sh2 : sh0); T[2] = c0 == 0 ? sh2 : (c0 == 1 ? sh0 : sh1); T[3] = T[0];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int e = e0 + b;
+            const int ix = ix0 + hx0 + ((c0 + b >= 3) ? 1 : 0);
+            float v = (float)((word[u] >> (8 * b)) & 0xffu) * S[b];
+            v = v + T[b];
+            const uint32_t keep = (rowin && (unsigned)ix < (unsigned)vw) ? 0xffffu : 0u;   // 0 outside the page
+            const int idx = (item && (unsigned)e < (unsigned)SEG) ? e : SEG;
+            hrow[idx] = (bf16_t)(f32_to_bf16(v) & keep);
+        }
+    }
+}
+
+// halo offsets of a lane's 16 K-indices (k = ks * 16 + h * 8 + j -> row kh = k / 9, element kr = k % 9), the same for every
+// pixel; the five padding indices (k >= 27) re-read element 0: their weights are zero and the data is finite
+template <int NROW>
+__device__ __forceinline__ void stem_koff(int h, int (&koff)[2][8]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + h * 8 + j, kh = k / 9;
+            koff[ks][j] = k < 27 ? kh * NROW + (k - kh * 9) : 0;
+        }
+}
+
 __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[256 * STAGE_PITCH > HH * ROW * 2 ? 256 * STAGE_PITCH : HH * ROW * 2];
     bf16_t* halo = reinterpret_cast<bf16_t*>(smem);
@@ -32,59 +115,9 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
     const int vw = p.valid_w_per_img ? p.valid_w_per_img[n_img] : p.valid_w;
     const int vh = p.valid_h;
 
-    // ---- stage + normalise the halo: aligned 4-byte loads of each halo row segment, bytes extracted in registers ----
+    // ---- stage + normalise the halo ----
     const int iy0 = tile_y * TH * 2 - 1, ix0 = tile_x * TW * 2 - 1;
-    {
-        constexpr int SEG = HW * 3;                       // 195 bytes of a halo row
-        constexpr int WPR = (SEG + 3) / 4 + 1;            // aligned words that can cover it (50)
-        const long long img_off = (long long)n_img * p.H * p.W * 3;   // addresses are aligned relative to p.x (allocation base), not to this image
-        const long long all_bytes = (long long)p.N * p.H * p.W * 3;
-        constexpr int NIT = (HH * WPR + 255) / 256;
-        // phase 1: all aligned words of this thread are requested back to back (one memory latency, not one per item)
-        uint32_t word[NIT];
-        long long a0s[NIT];
-#pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int i = tid + 256 * u;
-            const int hy = i / WPR, wi = i - hy * WPR;
-            const int iy = iy0 + hy;
-            word[u] = 0;
-            a0s[u] = 0;
-            if (i < HH * WPR && iy >= 0 && iy < vh) {
-                const long long seg0 = img_off + ((long long)iy * p.W + ix0) * 3;   // byte offset of the segment start (may be < 0 at x = -1)
-                const long long a0 = (seg0 & ~3ll) + 4ll * wi;                // aligned word this thread fetches
-                a0s[u] = a0;
-                if (a0 >= 0 && a0 + 4 <= all_bytes) word[u] = *reinterpret_cast<const uint32_t*>(p.x + a0);
-                else for (int b = 0; b < 4; ++b) if (a0 + b >= 0 && a0 + b < all_bytes) word[u] |= (uint32_t)p.x[a0 + b] << (8 * b);
-            }
-        }
-        // phase 2: normalise and scatter the bytes of each word into the bf16 halo
-#pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int i = tid + 256 * u;
-            if (i >= HH * WPR) break;
-            const int hy = i / WPR, wi = i - hy * WPR;
-            const int iy = iy0 + hy;
-            if (iy < 0 || iy >= vh) {                      // whole row outside the page: zeros (normalised space)
-                for (int b = 0; b < 4; ++b) { const int e = wi * 4 + b; if (e < SEG) halo[hy * ROW + e] = 0; }
-                continue;
-            }
-            const long long seg0 = img_off + ((long long)iy * p.W + ix0) * 3;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const long long e = a0s[u] + b - seg0;          // element index inside the row segment
-                if (e < 0 || e >= SEG) continue;
-                const int hx = (int)e / 3, c = (int)e - hx * 3;
-                const int ix = ix0 + hx;
-                float v = 0.f;
-                if (ix >= 0 && ix < vw) {
-                    v = (float)((word[u] >> (8 * b)) & 0xffu) * p.scale[c];
-                    v = v + p.shift[c];
-                }
-                halo[hy * ROW + (int)e] = f32_to_bf16(v);
-            }
-        }
-    }
+    fill_halo_u8<HH, HW, ROW>(halo, p, n_img, iy0, ix0, vh, vw, tid);
     __syncthreads();
 
     // ---- MFMA: D[cout][pixel] ----
@@ -93,19 +126,17 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[mt][j] = 0.f;
+    int koff[2][8];
+    stem_koff<ROW>(h, koff);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const bf16x8_t afr = *reinterpret_cast<const bf16x8_t*>(p.wpk + ((ks * 2 + h) * 32 + r) * 8);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int ty = wave * 2 + mt, tx = r;
+            const bf16_t* hb = halo + (2 * (wave * 2 + mt)) * ROW + 6 * r;
             union { bf16x8_t v; bf16_t s[8]; } b;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = ks * 16 + h * 8 + j;  // runtime in h only
-                const int kh = k / 9, kr = k - kh * 9;
-                b.s[j] = (k < 27) ? halo[(2 * ty + kh) * ROW + 6 * tx + kr] : (bf16_t)0;
-            }
+            for (int j = 0; j < 8; ++j) b.s[j] = hb[koff[ks][j]];
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, b.v, acc[mt], 0, 0, 0);
         }
     }
@@ -114,18 +145,27 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
     // ---- epilogue ----
     unsigned char* stage = smem;
 #pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + 8 * g + 4 * h);
+            acc[mt][4 * g + 0] += b4.x; acc[mt][4 * g + 1] += b4.y; acc[mt][4 * g + 2] += b4.z; acc[mt][4 * g + 3] += b4.w;
+        }
+    // the activation switch once per kernel, not once per element
+#define STEM_ALL(expr) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int j = 0; j < 16; ++j) { const float v = acc[mt][j]; acc[mt][j] = (expr); }
+    if (p.act == ACT_RELU) { STEM_ALL(fmaxf(v, 0.f)) }
+    else if (p.act == ACT_HSWISH) { STEM_ALL(v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f)) }
+    else if (p.act != ACT_NONE) { STEM_ALL(apply_act(v, p.act)) }
+#undef STEM_ALL
+#pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int tp = (wave * 2 + mt) * TW + r;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int cn = 8 * g + 4 * h;
-            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + cn);
-            const float v0 = apply_act(acc[mt][4 * g + 0] + b4.x, p.act), v1 = apply_act(acc[mt][4 * g + 1] + b4.y, p.act);
-            const float v2 = apply_act(acc[mt][4 * g + 2] + b4.z, p.act), v3 = apply_act(acc[mt][4 * g + 3] + b4.w, p.act);
             uint2 o;
-            o.x = pack_bf16x2(v0, v1);
-            o.y = pack_bf16x2(v2, v3);
-            *reinterpret_cast<uint2*>(stage + tp * STAGE_PITCH + cn * 2) = o;
+            o.x = pack_bf16x2(acc[mt][4 * g + 0], acc[mt][4 * g + 1]);
+            o.y = pack_bf16x2(acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
+            *reinterpret_cast<uint2*>(stage + tp * STAGE_PITCH + (8 * g + 4 * h) * 2) = o;
         }
     }
     __syncthreads();
@@ -170,45 +210,7 @@ __global__ __launch_bounds__(256) void stem12_kernel(const StemParams p, const b
     // ---- A: input region -> normalised bf16 halo ----
     const int y1_0 = tile_y * TH - 1, x1_0 = tile_x * TW - 1;   // conv1-output coordinates of the t1 tile's first pixel
     const int iy0 = 2 * y1_0 - 1, ix0 = 2 * x1_0 - 1;
-    {
-        constexpr int SEG = F_HW * 3, WPR = (SEG + 3) / 4 + 1, NIT = (F_HH * WPR + 255) / 256;
-        const long long img_off = (long long)n_img * p.H * p.W * 3, all_bytes = (long long)p.N * p.H * p.W * 3;
-        uint32_t word[NIT];
-        long long a0s[NIT];
-#pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int i = tid + 256 * u;
-            const int hy = i / WPR, wi = i - hy * WPR, iy = iy0 + hy;
-            word[u] = 0; a0s[u] = 0;
-            if (i < F_HH * WPR && iy >= 0 && iy < vh) {
-                const long long seg0 = img_off + ((long long)iy * p.W + ix0) * 3;
-                const long long a0 = (seg0 & ~3ll) + 4ll * wi;
-                a0s[u] = a0;
-                if (a0 >= 0 && a0 + 4 <= all_bytes) word[u] = *reinterpret_cast<const uint32_t*>(p.x + a0);
-                else for (int b = 0; b < 4; ++b) if (a0 + b >= 0 && a0 + b < all_bytes) word[u] |= (uint32_t)p.x[a0 + b] << (8 * b);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int i = tid + 256 * u;
-            if (i >= F_HH * WPR) break;
-            const int hy = i / WPR, wi = i - hy * WPR, iy = iy0 + hy;
-            if (iy < 0 || iy >= vh) {
-                for (int b = 0; b < 4; ++b) { const int e = wi * 4 + b; if (e < SEG) halo[hy * F_ROW + e] = 0; }
-                continue;
-            }
-            const long long seg0 = img_off + ((long long)iy * p.W + ix0) * 3;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const long long e = a0s[u] + b - seg0;
-                if (e < 0 || e >= SEG) continue;
-                const int hx = (int)e / 3, c = (int)e - hx * 3, ix = ix0 + hx;
-                float v = 0.f;
-                if (ix >= 0 && ix < vw) { v = (float)((word[u] >> (8 * b)) & 0xffu) * p.scale[c]; v = v + p.shift[c]; }
-                halo[hy * F_ROW + (int)e] = f32_to_bf16(v);
-            }
-        }
-    }
+    fill_halo_u8<F_HH, F_HW, F_ROW>(halo, p, n_img, iy0, ix0, vh, vw, tid);
     __syncthreads();
 
     // ---- B: conv1 (3 -> 32, stride 2) for the 340 pixels of the t1 tile ----
@@ -219,10 +221,13 @@ __global__ __launch_bounds__(256) void stem12_kernel(const StemParams p, const b
         float4 b1[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) b1[g] = *reinterpret_cast<const float4*>(p.bias + 8 * g + 4 * h);
+        int koff[2][8];
+        stem_koff<F_ROW>(h, koff);
         for (int tile = wave; tile * 32 < F_T1PX; tile += 4) {
             const int pidx = tile * 32 + r;
             const int pc = min(pidx, F_T1PX - 1);
             const int py = pc / F_T1W, px = pc - py * F_T1W;
+            const bf16_t* hb = halo + (2 * py) * F_ROW + 6 * px;
             f32x16_t acc;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.f;
@@ -230,11 +235,7 @@ __global__ __launch_bounds__(256) void stem12_kernel(const StemParams p, const b
             for (int ks = 0; ks < 2; ++ks) {
                 union { bf16x8_t v; bf16_t s[8]; } b;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = ks * 16 + h * 8 + j;
-                    const int kh = k / 9, kr = k - kh * 9;
-                    b.s[j] = (k < 27) ? halo[(2 * py + kh) * F_ROW + 6 * px + kr] : (bf16_t)0;
-                }
+                for (int j = 0; j < 8; ++j) b.s[j] = hb[koff[ks][j]];
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], b.v, acc, 0, 0, 0);
             }
             const int y1 = y1_0 + py, x1 = x1_0 + px;
@@ -245,8 +246,8 @@ __global__ __launch_bounds__(256) void stem12_kernel(const StemParams p, const b
                 for (int g = 0; g < 4; ++g) {
                     uint2 o = make_uint2(0, 0);
                     if (inimg) {
-                        o.x = pack_bf16x2(apply_act(acc[4 * g + 0] + b1[g].x, p.act), apply_act(acc[4 * g + 1] + b1[g].y, p.act));
-                        o.y = pack_bf16x2(apply_act(acc[4 * g + 2] + b1[g].z, p.act), apply_act(acc[4 * g + 3] + b1[g].w, p.act));
+                        o.x = pack_bf16x2(fmaxf(acc[4 * g + 0] + b1[g].x, 0.f), fmaxf(acc[4 * g + 1] + b1[g].y, 0.f));   // ReLU (checked at launch)
+                        o.y = pack_bf16x2(fmaxf(acc[4 * g + 2] + b1[g].z, 0.f), fmaxf(acc[4 * g + 3] + b1[g].w, 0.f));
                     }
                     *reinterpret_cast<uint2*>(t1 + pidx * 64 + ((g ^ swz) * 16) + 8 * h) = o;
                 }
@@ -353,7 +354,7 @@ hipError_t stem_conv_launch(const StemParams& p, hipStream_t stream) {
 }
 
 hipError_t stem12_launch(const StemParams& p, const bf16_t* w2pk, const float* bias2, hipStream_t stream) {
-    if (p.valid_w_per_img != nullptr || p.Cout_store != 32) return hipErrorInvalidValue;
+    if (p.valid_w_per_img != nullptr || p.Cout_store != 32 || p.act != ACT_RELU) return hipErrorInvalidValue;
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
     hipLaunchKernelGGL(stem12_kernel, dim3(p.N * tiles_x * tiles_y), dim3(256), 0, stream, p, w2pk, bias2);
     return hipGetLastError();
