@@ -146,7 +146,7 @@ def main():
         pmc = json.loads((ROOT / "profiles" / "r01_pmc_hbm.json").read_text())
         want = dom.replace(" ", "")
         for name, v in pmc.get("all", pmc).items():     # rocprofv3 prints "conv_ring_kernel<1, false>(ConvParams, ...)"
-            flat = name.replace(" ", "").replace(",false>", ">")
+            flat = name.replace(" ", "").replace(",false,false>", ">")
             if want in flat:
                 traffic = v.get("hbm_bytes_per_launch")
     except Exception:

@@ -41,7 +41,7 @@ struct RingTile { int n_img, ntile, oyb, oxb; };
 __device__ __forceinline__ bf16x8_t ring_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 
 // PROF (developer tool, LUMINA_RING_PROF=1): per-phase core-clock sums of every wave -> prof[0..7] (see conv_ring_launch)
-template <int TR, bool PROF = false>
+template <int TR, bool PROF = false, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, const int total_tiles, const int per_xcd, const int wg_per_xcd,
                                                            unsigned long long* prof) {
     long long t_wait = 0, t_bar = 0, t_issue = 0, t_comp = 0, t_epi = 0, t0 = 0, t1 = 0;
@@ -70,6 +70,9 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
         const int trem = mtile - t.n_img * tiles_per_img;
         const int ty = trem / p.tiles_x;
         t.oyb = ty * R_TH; t.oxb = (trem - ty * p.tiles_x) * R_TW;
+        // fused 3x3/s2 max pool: a tile yields 7 x 15 pooled pixels from conv rows / columns 2q - 1 .. 2q + 1: tiles step by
+        // 14 x 30 conv pixels and start one row / column early (82 % of the MFMA work is net, the un-pooled tensor is never written)
+        if constexpr (POOL) { t.oyb = ty * (R_TH - 2) - 1; t.oxb = (trem - ty * p.tiles_x) * (R_TW - 2) - 1; }
         return t;
     };
 
@@ -162,6 +165,23 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
     RingTile done{};
     bool pending = false;
     auto store_done = [&]() {
+        if constexpr (POOL) {   // pk[0] / pk[1] = pooled rows 2 * wave, 2 * wave + 1 of the tile; even lanes hold pooled column r / 2
+            const int Hq = (p.H - 1) / 2 + 1, Wq = (p.W - 1) / 2 + 1;
+            const int px = (done.oxb + 1) / 2 + (r >> 1);
+            if ((r & 1) || (r >> 1) >= (R_TW - 2) / 2 || px >= Wq) return;
+            bf16_t* yimg = p.y + (size_t)done.n_img * Hq * Wq * p.y_cstride + p.y_coff + done.ntile * R_BN + 8 * h;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int prow = 2 * wave + pr, py = (done.oyb + 1) / 2 + prow;
+                if (prow >= (R_TH - 2) / 2 || py >= Hq) continue;
+                bf16_t* ypix = yimg + (py * Wq + px) * p.y_cstride;
+#pragma unroll
+                for (int nt = 0; nt < R_NT; ++nt)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) *reinterpret_cast<uint4*>(ypix + nt * 32 + 16 * gp) = pk[pr][nt][gp];
+            }
+            return;
+        }
         bf16_t* yimg = p.y + (size_t)done.n_img * p.H * p.W * p.y_cstride + p.y_coff + done.ntile * R_BN + 8 * h;
         const int ox = done.oxb + r;
 #pragma unroll
@@ -181,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
     // would make hipcc drain the in-flight DMA at its first use.
     const float* sBias = reinterpret_cast<const float*>(smem + 2 * R_BUF);
     RingTile cur{};
-    auto epilogue = [&](auto has_res_t) {
+    auto epilogue = [&](auto has_res_t, int free_slot) {
         constexpr bool HAS_RES = decltype(has_res_t)::value;
         const float* bsrc = sBias + cur.ntile * R_BN + 4 * h;
         const bf16_t* rimg = HAS_RES ? p.res + (size_t)cur.n_img * p.H * p.W * p.res_cstride + cur.ntile * R_BN + 4 * h : nullptr;
@@ -227,8 +247,50 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
                     const auto sx2 = __builtin_amdgcn_permlane32_swap(q0x, q1x, false, false);
                     const auto sy2 = __builtin_amdgcn_permlane32_swap(q0y, q1y, false, false);
                     pk[mt][nt][gp] = make_uint4(sx2[0], sy2[0], sx2[1], sy2[1]);
+                    if constexpr (POOL) {   // conv pixels outside the map are pool padding: ReLU output is >= 0, so 0 is neutral
+                        const int oy = cur.oyb + wave * R_MT + mt;
+                        const uint32_t keep = (oy >= 0 && oy < LH && ox >= 0 && ox < LW) ? 0xffffffffu : 0u;
+                        pk[mt][nt][gp].x &= keep; pk[mt][nt][gp].y &= keep; pk[mt][nt][gp].z &= keep; pk[mt][nt][gp].w &= keep;
+                    }
                 }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (POOL) {
+            // 3x3/s2 max pool on the packed bf16 values.  After ReLU they are >= +0, where bf16 bit patterns order like signed
+            // 16-bit integers: v_pk_max_i16 is the float max.  Vertical: wave w owns conv rows 4w..4w+3 -> pooled row 2w is local
+            // (rows 0,1,2), pooled row 2w+1 needs row 0 of wave w+1, handed over through the ring slot that was just consumed
+            // (two barriers: its readers are done / the rows are there).  Horizontal: even lane r takes lanes r, r+1, r+2.
+            typedef short s16x2_t __attribute__((ext_vector_type(2)));
+            auto mx = [](uint32_t a, uint32_t b) {
+                const s16x2_t m = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b));
+                return __builtin_bit_cast(uint32_t, m);
+            };
+            auto mx4 = [&](const uint4& a, const uint4& b) { return make_uint4(mx(a.x, b.x), mx(a.y, b.y), mx(a.z, b.z), mx(a.w, b.w)); };
+            auto hmax = [&](uint32_t v) {
+                const uint32_t v1 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + 1) * 4, (int)v);
+                const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + 2) * 4, (int)v);
+                return mx(mx(v, v1), v2);
+            };
+            unsigned char* exch = smem + free_slot;
+            __syncthreads();
+            if (wave > 0) {
+#pragma unroll
+                for (int nt = 0; nt < R_NT; ++nt)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) *reinterpret_cast<uint4*>(exch + (wave - 1) * 4096 + ((nt * 2 + gp) * 64 + lane) * 16) = pk[0][nt][gp];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < R_NT; ++nt)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    uint4 nb = make_uint4(0, 0, 0, 0);
+                    if (wave < 3) nb = *reinterpret_cast<const uint4*>(exch + wave * 4096 + ((nt * 2 + gp) * 64 + lane) * 16);
+                    const uint4 top = mx4(mx4(pk[0][nt][gp], pk[1][nt][gp]), pk[2][nt][gp]);
+                    const uint4 bot = mx4(mx4(pk[2][nt][gp], pk[3][nt][gp]), nb);
+                    pk[0][nt][gp] = make_uint4(hmax(top.x), hmax(top.y), hmax(top.z), hmax(top.w));
+                    pk[1][nt][gp] = make_uint4(hmax(bot.x), hmax(bot.y), hmax(bot.z), hmax(bot.w));
+                }
         }
     };
 
@@ -274,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
         }
 
         // ---- epilogue in registers: + bias (+ residual), activation, bf16, 16-byte pieces ----
-        if (p.res != nullptr) epilogue(std::true_type{}); else epilogue(std::false_type{});
+        if (!POOL && p.res != nullptr) epilogue(std::true_type{}, R_BUF - boff); else epilogue(std::false_type{}, R_BUF - boff);   // boff was toggled: R_BUF - boff is the slot just consumed
         RING_T(t_epi)
         done = cur; pending = true;
         lid = next_lid;
@@ -302,7 +364,8 @@ bool conv_ring_supported(const ConvKernelCfg& cfg, const ConvParams& p) {
     static const bool off = getenv("LUMINA_CONV_NO_RING") != nullptr;
     if (off) return false;
     if (!(cfg.nw == 6 && cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16)) return false;
-    if (p.out_mode != OUT_NORMAL || p.pix_limit != 0 || p.gate != nullptr || p.zeros == nullptr) return false;
+    if ((p.out_mode != OUT_NORMAL && p.out_mode != OUT_POOL) || p.pix_limit != 0 || p.gate != nullptr || p.zeros == nullptr) return false;
+    if (p.out_mode == OUT_POOL && (p.act != ACT_RELU || p.res != nullptr)) return false;   // the pool compares bf16 bit patterns: values must be >= 0
     if (p.Cin < 32 || p.Cin % 16 != 0 || p.Cout % 64 != 0 || p.Cout * 4 > R_BIAS_BYTES || p.Ho != p.H || p.Wo != p.W) return false;
     if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
     if (p.res != nullptr && (p.res_shift != 0 || p.res_h != p.H || p.res_w != p.W || p.res_cstride % 4 != 0 || (long long)p.H * p.W * p.res_cstride >= (1ll << 31))) return false;
@@ -313,6 +376,7 @@ bool conv_ring_supported(const ConvKernelCfg& cfg, const ConvParams& p) {
 
 // orientation: -1 = whichever pads less (ties: lanes along the image rows), 0 / 1 forced (tests)
 bool conv_ring_transposed(const ConvParams& p, int orientation) {
+    if (p.out_mode == OUT_POOL) return false;   // the pooled variant is built for one orientation
     auto padded = [&](int lh, int lw) { return (long long)ceil_div(lh, R_TH) * R_TH * ceil_div(lw, R_TW) * R_TW; };
     return orientation < 0 ? padded(p.W, p.H) < padded(p.H, p.W) : orientation != 0;
 }
@@ -320,7 +384,9 @@ bool conv_ring_transposed(const ConvParams& p, int orientation) {
 hipError_t conv_ring_launch(ConvParams p, int orientation, hipStream_t stream) {
     const bool tr = conv_ring_transposed(p, orientation);
     const int lh = tr ? p.W : p.H, lw = tr ? p.H : p.W;
+    const bool pool = p.out_mode == OUT_POOL;
     p.tiles_y = ceil_div(lh, R_TH); p.tiles_x = ceil_div(lw, R_TW); p.n_tiles = p.Cout / R_BN;
+    if (pool) { p.tiles_y = ceil_div((p.H - 1) / 2 + 1, (R_TH - 2) / 2); p.tiles_x = ceil_div((p.W - 1) / 2 + 1, (R_TW - 2) / 2); }
     const long long total = (long long)p.N * p.tiles_x * p.tiles_y * p.n_tiles;
     if (total <= 0 || total >= (1ll << 31)) return hipErrorInvalidValue;
     const int per_xcd = (int)((total + 7) / 8);
@@ -332,7 +398,7 @@ hipError_t conv_ring_launch(ConvParams p, int orientation, hipStream_t stream) {
     static const bool prof = getenv("LUMINA_RING_PROF") != nullptr;
     static const int dbg = getenv("LUMINA_CONV_DBG") ? atoi(getenv("LUMINA_CONV_DBG")) : 0;
     p.dbg_skip = dbg;
-    if (prof) {   // developer tool: where do the waves' cycles go (synchronises, prints one line per launch)
+    if (prof && !pool) {   // developer tool: where do the waves' cycles go (synchronises, prints one line per launch)
         static unsigned long long* dprof = nullptr;
         if (!dprof && hipMalloc(&dprof, 64) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(dprof, 0, 64, stream);
@@ -349,15 +415,18 @@ hipError_t conv_ring_launch(ConvParams p, int orientation, hipStream_t stream) {
                 p.H, p.W, p.Cin, p.Cout, (int)tr, total, w, all / w, 100.0 * hp[0] / all, 100.0 * hp[1] / all, 100.0 * hp[2] / all, 100.0 * hp[3] / all, 100.0 * hp[4] / all);
         return hipGetLastError();
     }
-    static bool attr_done[2] = {false, false};
-    const void* fn = tr ? reinterpret_cast<const void*>(conv_ring_kernel<1>) : reinterpret_cast<const void*>(conv_ring_kernel<0>);
-    if (!attr_done[tr]) {
+    static bool attr_done[3] = {false, false, false};
+    const int which = pool ? 2 : (int)tr;
+    const void* fn = pool ? reinterpret_cast<const void*>(conv_ring_kernel<0, false, true>)
+                          : (tr ? reinterpret_cast<const void*>(conv_ring_kernel<1>) : reinterpret_cast<const void*>(conv_ring_kernel<0>));
+    if (!attr_done[which]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
         if (e != hipSuccess) return e;
-        attr_done[tr] = true;
+        attr_done[which] = true;
     }
     unsigned long long* none = nullptr;
-    if (tr) hipLaunchKernelGGL((conv_ring_kernel<1>), dim3(8 * wg_per_xcd), dim3(256), R_LDS, stream, p, (int)total, per_xcd, wg_per_xcd, none);
+    if (pool) hipLaunchKernelGGL((conv_ring_kernel<0, false, true>), dim3(8 * wg_per_xcd), dim3(256), R_LDS, stream, p, (int)total, per_xcd, wg_per_xcd, none);
+    else if (tr) hipLaunchKernelGGL((conv_ring_kernel<1>), dim3(8 * wg_per_xcd), dim3(256), R_LDS, stream, p, (int)total, per_xcd, wg_per_xcd, none);
     else hipLaunchKernelGGL((conv_ring_kernel<0>), dim3(8 * wg_per_xcd), dim3(256), R_LDS, stream, p, (int)total, per_xcd, wg_per_xcd, none);
     return hipGetLastError();
 }
