@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void resample_h_rgb_kernel(const uint8_t* in, 
             int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
 #pragma unroll
             for (int j = 0; j < HK; ++j) {  // straight-line: taps beyond the pixel's count have coefficient 0 (reads stay inside the LDS slack)
-                s0 += (int)p[3 * j] * kreg[j]; s1 += (int)p[3 * j + 1] * kreg[j]; s2 += (int)p[3 * j + 2] * kreg[j];
+                s0 += __mul24((int)p[3 * j], kreg[j]); s1 += __mul24((int)p[3 * j + 1], kreg[j]); s2 += __mul24((int)p[3 * j + 2], kreg[j]);   // |coefficient| < 2^23: v_mad_i32_i24 (v_mul_lo_u32 is quarter rate)
             }
             s0 >>= PRECISION_BITS; s1 >>= PRECISION_BITS; s2 >>= PRECISION_BITS;
             const long long go = ((long long)(row0 + r) * Wo + xo0) * 3;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void resample_v_tile_kernel(const uint8_t* in,
             const uint32_t* lr = lds + r * VT_PITCH + (off >> 2);
             const uint32_t w = __builtin_amdgcn_alignbyte(lr[1], lr[0], (uint32_t)(off & 3));
             const int kj = kl[rr * VK + j];
-            s0 += (int)(w & 0xff) * kj; s1 += (int)((w >> 8) & 0xff) * kj; s2 += (int)((w >> 16) & 0xff) * kj; s3 += (int)(w >> 24) * kj;
+            s0 += __mul24((int)(w & 0xff), kj); s1 += __mul24((int)((w >> 8) & 0xff), kj); s2 += __mul24((int)((w >> 16) & 0xff), kj); s3 += __mul24((int)(w >> 24), kj);
         }
         s0 >>= PRECISION_BITS; s1 >>= PRECISION_BITS; s2 >>= PRECISION_BITS; s3 >>= PRECISION_BITS;
         const uint32_t res = (uint32_t)(s0 < 0 ? 0 : (s0 > 255 ? 255 : s0)) | ((uint32_t)(s1 < 0 ? 0 : (s1 > 255 ? 255 : s1)) << 8) |
