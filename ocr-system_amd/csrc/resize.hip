@@ -244,10 +244,9 @@ __global__ __launch_bounds__(256) void gray_sum_kernel(const uint8_t* img, unsig
 
 __device__ __forceinline__ uint8_t blend_u8(int deg, int v, float alpha) {
     const float t = __fadd_rn((float)deg, __fmul_rn(alpha, (float)(v - deg)));
-    if (alpha >= 0.f && alpha <= 1.f) return (uint8_t)t;
-    if (t <= 0.f) return 0;
-    if (t >= 255.f) return 255;
-    return (uint8_t)t;
+    // PIL clips only when alpha is outside [0, 1]; inside, t already lies between the two byte values, so one unconditional
+    // clamp (v_med3_f32) is the same function without a per-byte branch
+    return (uint8_t)fminf(fmaxf(t, 0.f), 255.f);
 }
 
 // Fused contrast + sharpness.  One workgroup = EN_R rows x EN_XB row bytes.  The contrast-blended bytes of the EN_R + 2 rows
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(256) void enhance_kernel(const uint8_t* img, uint8_
             a = __fadd_rn(a, __fmul_rn(WB(0, j + 3), k1));
             a = __fadd_rn(a, __fmul_rn(WB(0, j + 6), k1));
             ss = __fadd_rn(ss, a);
-            const int sm = ss <= 0.f ? 0 : (ss >= 255.f ? 255 : (int)ss);
+            const int sm = (int)fminf(fmaxf(ss, 0.f), 255.f);
             const int deg = (yin && e >= 3 && e < rowb - 3) ? sm : v;
             res |= (uint32_t)blend_u8(deg, v, alpha_s) << (8 * j);
         }
