@@ -65,8 +65,8 @@ def cpu_baseline(det_w, rec_w, charset, n_pages=6):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pages", type=int, default=PAGES_PER_RANK, help="pages per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--det-sub-batch", type=int, default=16)

@@ -36,6 +36,7 @@ int lumina_ocr_create(int device, lumina_ocr_t** out) {
     if (hipSetDevice(device) != hipSuccess) { eng->err = "hipSetDevice failed"; *out = eng; return 2; }
     if (const char* e = getenv("LUMINA_RING_ORIENT")) eng->ring_orient = atoi(e) < 0 ? -1 : (atoi(e) != 0);   // developer A/B (profiler runs)
     if (getenv("LUMINA_CONV_NO_RING")) eng->conv_ring = false;
+    if (getenv("LUMINA_BLOCKED")) eng->blocked_layout = atoi(getenv("LUMINA_BLOCKED")) != 0;
     *out = eng;
     return 0;
 }
@@ -62,6 +63,7 @@ int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value) {
     else if (!strcmp(key, "fuse_pool")) h->fuse_pool = value != 0;
     else if (!strcmp(key, "fuse_stem")) h->fuse_stem = value != 0;
     else if (!strcmp(key, "conv_ring")) h->conv_ring = value != 0;
+    else if (!strcmp(key, "blocked_layout")) h->blocked_layout = value != 0;
     else if (!strcmp(key, "conv_big_min")) h->conv_big_min = value >= 0 ? value : 1024;
     else if (!strcmp(key, "ring_orient")) h->ring_orient = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "post_group")) h->post_group = value > 0 ? value : 1;

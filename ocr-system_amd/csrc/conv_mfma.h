@@ -36,6 +36,9 @@ struct ConvParams {
     int dbg_skip;   // timing experiments only (LUMINA_CONV_DBG): 1 skip weight reloads, 2 skip halo reloads, 8 channel-blocked addressing (wrong results); 32 = staged epilogue everywhere
     int pix_limit;  // flat-GEMM mode (1x1): pixels >= pix_limit of an image are neither read nor written (0 = off)
     const bf16_t* zeros;  // >= 16 bytes of zeros in device memory (LDS-DMA variant: source of the out-of-image halo)
+    // channel-blocked tensors [n][C/16][H][W][16] (conv_ring.hip only): a 16-channel chunk of a pixel row is contiguous, every
+    // chunk pass of the K loop touches its own cache lines exactly once (NHWC: 32 bytes of every 128-byte line per pass)
+    int x_blk, y_blk, res_blk;
 };
 
 struct ConvKernelCfg {

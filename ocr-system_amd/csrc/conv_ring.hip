@@ -56,6 +56,8 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
     const int sy = TR ? 1 : p.W, sx = TR ? p.W : 1;
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int nchunks = p.Cin >> 4;
+    const int hw = p.H * p.W;
+    const int chunk_adv = p.x_blk ? hw * 16 : 16;   // elements from one 16-channel chunk of the input to the next
 
     const int xcd = blockIdx.x & 7;
     int lid = xcd * per_xcd + (blockIdx.x >> 3);
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
             const int hy = pi / R_HW, hx = pi - hy * R_HW;
             const int ly = t.oyb - 1 + hy, lx = t.oxb - 1 + hx;
             const bool inb = i < R_A_ITEMS && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
-            a_goff[it] = inb ? (ly * sy + lx * sx) * p.Cin + c * 8 : -1;
+            a_goff[it] = inb ? (ly * sy + lx * sx) * (p.x_blk ? 16 : p.Cin) + c * 8 : -1;
             if (PROF && (p.dbg_skip & 8)) a_goff[it] = i * 8;   // timing experiment: a perfectly coalesced halo (wrong values)
         }
     };
@@ -182,17 +184,19 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
             }
             return;
         }
-        bf16_t* yimg = p.y + (size_t)done.n_img * p.H * p.W * p.y_cstride + p.y_coff + done.ntile * R_BN + 8 * h;
+        // NHWC: pixel stride y_cstride, the 16-byte pieces of a pixel 16 channels apart; blocked: pixel stride 16, pieces hw * 16 apart
+        const int ypix_stride = p.y_blk ? 16 : p.y_cstride, yblk_stride = p.y_blk ? hw * 16 : 16;
+        bf16_t* yimg = p.y + (size_t)done.n_img * hw * p.y_cstride + (p.y_blk ? (p.y_coff + done.ntile * R_BN) / 16 * (hw * 16) : p.y_coff + done.ntile * R_BN) + 8 * h;
         const int ox = done.oxb + r;
 #pragma unroll
         for (int mt = 0; mt < R_MT; ++mt) {
             const int oy = done.oyb + wave * R_MT + mt;
             if (oy >= LH || ox >= LW) continue;
-            bf16_t* ypix = yimg + (oy * sy + ox * sx) * p.y_cstride;
+            bf16_t* ypix = yimg + (oy * sy + ox * sx) * ypix_stride;
 #pragma unroll
             for (int nt = 0; nt < R_NT; ++nt)
 #pragma unroll
-                for (int gp = 0; gp < 2; ++gp) *reinterpret_cast<uint4*>(ypix + nt * 32 + 16 * gp) = pk[mt][nt][gp];
+                for (int gp = 0; gp < 2; ++gp) *reinterpret_cast<uint4*>(ypix + (nt * 2 + gp) * yblk_stride) = pk[mt][nt][gp];
         }
     };
 
@@ -204,16 +208,17 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
     auto epilogue = [&](auto has_res_t, int free_slot) {
         constexpr bool HAS_RES = decltype(has_res_t)::value;
         const float* bsrc = sBias + cur.ntile * R_BN + 4 * h;
-        const bf16_t* rimg = HAS_RES ? p.res + (size_t)cur.n_img * p.H * p.W * p.res_cstride + cur.ntile * R_BN + 4 * h : nullptr;
+        const int rpix_stride = p.res_blk ? 16 : p.res_cstride, rblk_stride = p.res_blk ? hw * 16 : 16;   // as for the output
+        const bf16_t* rimg = HAS_RES ? p.res + (size_t)cur.n_img * hw * p.res_cstride + (p.res_blk ? cur.ntile * (R_BN / 16) * (hw * 16) : cur.ntile * R_BN) + 4 * h : nullptr;
         const int ox = cur.oxb + r;
         uint2 rr[2][R_NT][4];
         auto load_res = [&](int set, int mt) {
             const int oy = cur.oyb + wave * R_MT + mt;
-            const bf16_t* rpix = rimg + ((oy < LH && ox < LW) ? oy * sy + ox * sx : 0) * p.res_cstride;
+            const bf16_t* rpix = rimg + ((oy < LH && ox < LW) ? oy * sy + ox * sx : 0) * rpix_stride;
 #pragma unroll
             for (int nt = 0; nt < R_NT; ++nt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) rr[set][nt][g] = *reinterpret_cast<const uint2*>(rpix + nt * 32 + 8 * g);
+                for (int g = 0; g < 4; ++g) rr[set][nt][g] = *reinterpret_cast<const uint2*>(rpix + (nt * 2 + (g >> 1)) * rblk_stride + 8 * (g & 1));
         };
         if constexpr (HAS_RES) load_res(0, 0);
 #pragma unroll
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
         RING_T(t_wait)
         __syncthreads();
         RING_T(t_bar)
-        xa_n += 16; ws_n += R_W_ITEMS * 8;     // nchunks >= 2: request chunk 1
+        xa_n += chunk_adv; ws_n += R_W_ITEMS * 8;     // nchunks >= 2: request chunk 1
         if (pending) store_done();
         RING_T(t_issue)
         RING_COMPUTE(boff, R_BUF - boff, true)    // first tap: C = 0 (the accumulators are not cleared separately)
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
             __syncthreads();
             RING_T(t_bar)
             if (chunk + 1 < nchunks) {
-                xa_n += 16; ws_n += R_W_ITEMS * 8;
+                xa_n += chunk_adv; ws_n += R_W_ITEMS * 8;
             } else if (next_lid < lid_end) {   // the ring runs on into the next tile
                 nxt = decode(next_lid);
                 describe(nxt); rebase(nxt);
@@ -371,6 +376,7 @@ bool conv_ring_supported(const ConvKernelCfg& cfg, const ConvParams& p) {
     if (p.res != nullptr && (p.res_shift != 0 || p.res_h != p.H || p.res_w != p.W || p.res_cstride % 4 != 0 || (long long)p.H * p.W * p.res_cstride >= (1ll << 31))) return false;
     if ((long long)p.H * p.W * (p.Cin > p.y_cstride ? p.Cin : p.y_cstride) >= (1ll << 31)) return false;   // 32-bit per-image offsets
     if (p.y_cstride % 8 != 0 || p.y_coff % 8 != 0) return false;
+    if ((p.y_blk && (p.y_cstride % 16 != 0 || p.y_coff % 16 != 0 || p.out_mode != OUT_NORMAL)) || (p.res_blk && p.res_cstride % 16 != 0)) return false;
     return true;
 }
 

@@ -13,6 +13,7 @@
 struct Tensor4 {
     bf16_t* p = nullptr;
     int n = 0, h = 0, w = 0, c = 0;
+    bool blk = false;  // channel-blocked layout [n][c/16][h][w][16] instead of NHWC (conv_mfma.h: ConvParams::x_blk)
     size_t elems() const { return (size_t)n * h * w * c; }
 };
 
@@ -85,6 +86,7 @@ struct lumina_ocr {
     bool fuse_head = true;  // head.convt3 fused into head.convt2's epilogue
     bool fuse_pool = true;  // stem.conv3's epilogue does the 3x3/s2 max pool
     int conv_big_min = 1024;  // 16x32-tile kernels once a full sub-batch gives at least this many work-groups
+    bool blocked_layout = false;  // stage-0 activations in channel-blocked layout (experiment)
     bool conv_ring = true;  // persistent ring kernel for the 3x3 / stride-1 layers (conv_ring.hip)
     int ring_orient = -1;   // its tile orientation: -1 auto, 0 / 1 forced (tests)
     bool fuse_stem = true;  // stem.conv1 + stem.conv2 in one kernel (the first 32-channel tensor stays in LDS)

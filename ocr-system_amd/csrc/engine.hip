@@ -226,6 +226,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         if (res) { p.res_h = res->h; p.res_w = res->w; }
     }
     p.res_shift = res_shift;
+    p.x_blk = x.blk; p.y_blk = y->blk; p.res_blk = res ? res->blk : 0;
     p.res_cstride = res ? res->c : 0;
     p.y_cstride = y_cstride ? y_cstride : y->c;
     p.y_coff = y_coff;
@@ -251,6 +252,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     static const bool no_pw = getenv("LUMINA_CONV_NO_PW") != nullptr;
     const bool use_pw = !no_pw && !use_big && conv_pw_supported(cfg, p);
     const bool use_ring = eng->conv_ring && use_big && !use_pw && conv_ring_supported(cfg, p);
+    if (!use_ring && (p.x_blk || p.y_blk || p.res_blk)) return locr_fail(eng, "a channel-blocked tensor reached a kernel that cannot address it", L.name.c_str());
     hipError_t e = use_ring ? conv_ring_launch(p, eng->ring_orient, st) : (use_pw ? conv_pw_launch(p, st) : conv_launch(cfg, p, st));
     if (e != hipSuccess) return locr_fail(eng, L.name.c_str(), hipGetErrorString(e));
     if (eng->time_convs) {
@@ -321,6 +323,8 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
             const std::string p = "s" + std::to_string(i) + ".b" + std::to_string(j);
             const int stride = (i > 0 && j == 0) ? 2 : 1;
             Tensor4 y = ws_tensor(eng, B, x.h / stride, x.w / stride, chs[i]);
+            const bool blk = i == 0 && eng->blocked_layout && !eng->keep_taps;   // stage-0 tensors that only the ring kernel touches
+            y.blk = blk;
             RUN(eng_run_conv(eng, D[p + ".conv0"], x, &y, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st));
             Tensor4 sc = x;
             if (j == 0) {
@@ -328,6 +332,7 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
                 RUN(eng_run_conv(eng, D[p + ".short"], x, &sc, nullptr, 0, OUT_NORMAL, 0, 0, 0, i == 0, st));
             }
             Tensor4 o = ws_tensor(eng, B, y.h, y.w, chs[i]);
+            o.blk = blk && j == 0;
             RUN(eng_run_conv(eng, D[p + ".conv1"], y, &o, &sc, 0, OUT_NORMAL, 0, 0, 0, false, st));
             tap(eng, p.c_str(), o);
             x = o;

@@ -215,6 +215,27 @@ def test_ring_conv_kernel_is_bit_identical(engine, det_weights, shape, orient):
     assert torch.equal(a, ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901)], ids=lambda s: "b%d_%dx%d" % s)
+def test_channel_blocked_stage0_tensors_are_bit_identical(engine, det_weights, shape):
+    """Engine option blocked_layout (an experiment): the stage-0 tensors that only the ring kernel reads and
+    writes are stored [n][C/16][H][W][16] instead of NHWC — input halo, residual and output addressing change, the
+    arithmetic does not."""
+    b, h, w = shape
+    pages = torch.from_numpy(_pages(b, h, w, 43)).cuda()
+    engine.load_det(det_weights)
+    engine.set_option("conv_big_min", 1)
+    try:
+        engine.set_option("blocked_layout", 0)
+        ref = engine.det_forward(pages).clone()
+        engine.set_option("blocked_layout", 1)
+        a = engine.det_forward(pages).clone()
+    finally:
+        engine.set_option("blocked_layout", 0)
+        engine.set_option("conv_big_min", 1024)
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref)
+
+
 def test_page_result_is_independent_of_batch_size(engine, det_weights):
     """The kernel variant of every layer is chosen from the layer geometry and the configured sub-batch, never from the number
     of pages in the call (different tilings sum the same products in a different order): one page alone == the same page in a batch."""
