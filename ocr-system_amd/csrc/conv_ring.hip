@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
         if (lid >= lid_end) break;
         cur = nxt;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the spare request of the last chunk must not outlive the workgroup's LDS
     store_done();
     if constexpr (PROF) {
         if (lane == 0) {
