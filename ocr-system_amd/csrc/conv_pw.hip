@@ -77,6 +77,13 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvParams p, con
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                   \
             afr[ks][nt] = *reinterpret_cast<const bf16x8_t*>(p.wpk + ((((size_t)(q_) * nchunks + (ks >> 1)) * 4 + 2 * (ks & 1) + h) * 64 + nt * 32 + r) * 8);
     LOAD_W(0)
+    // fused tail: the 64 -> 4 weights of the last transposed conv are the same for every group and pixel: once per workgroup
+    // (inside the loop hipcc cannot hoist them past the stores and re-reads them 32 times per tile)
+    bf16x8_t w3fr[4];
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) w3fr[ks] = *reinterpret_cast<const bf16x8_t*>(p.fuse_w + ((ks * 2 + h) * 32 + r) * 8);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -223,8 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvParams p, con
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const bf16x8_t bfr = ldsf(stage + tp * PW_STAGE_PITCH + (ks * 16 + h * 8) * 2);
-                    const bf16x8_t wfr = *reinterpret_cast<const bf16x8_t*>(p.fuse_w + ((ks * 2 + h) * 32 + r) * 8);
-                    d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, bfr, d2, 0, 0, 0);
+                    d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3fr[ks], bfr, d2, 0, 0, 0);
                 }
                 if (h == 0 && pvalid[mt]) {
                     const int yy = 4 * oy[mt] + 2 * (q >> 1), xx = 4 * ox[mt] + 2 * (q & 1);
