@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
             const int hy = pi / R_HW, hx = pi - hy * R_HW;
             const int ly = t.oyb - 1 + hy, lx = t.oxb - 1 + hx;
             const bool inb = i < R_A_ITEMS && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
-            a_goff[it] = inb ? (ly * sy + lx * sx) * (p.x_blk ? 16 : p.Cin) + c * 8 : -1;
+            const int cs = c ^ ((hx >> 3) & 1);   // LDS slot c of this pixel holds slice cs (bank swizzle, see the fragment reads)
+            a_goff[it] = inb ? (ly * sy + lx * sx) * (p.x_blk ? 16 : p.Cin) + cs * 8 : -1;
             if (PROF && (p.dbg_skip & 8)) a_goff[it] = i * 8;   // timing experiment: a perfectly coalesced halo (wrong values)
         }
     };
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
     auto dma_w = [&](int it, const bf16_t* wsrc, int tgt) {
         const int i = tid + 256 * it;
         if ((R_W_ITEMS % 256 == 0 || (it + 1) * 256 <= R_W_ITEMS || wave < (R_W_ITEMS % 256) / 64) && !(PROF && (p.dbg_skip & 1)))
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 8),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (i ^ ((i >> 4) & 1)) * 8),   // the two slices of a row swapped for rows 8..15 (mod 16)
                 (__attribute__((address_space(3))) void*)(smem + R_A_BYTES + tgt + (i - lane) * 16), 16, 0, 0);
     };
     static_assert(R_W_ITEMS % 64 == 0, "weight pieces split on wave boundaries");
@@ -124,42 +125,55 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
 
     f32x16_t acc[R_MT][R_NT];
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int aoff = h * 16 + ((wave * R_MT) * R_HW + r) * 32;   // + mt * R_HW * 32 + tap offset
-    const int woff = R_A_BYTES + h * 16 + r * 32;                // + (tap * 64 + nt * 32) * 32
+    // Fragment read bases.  A 32x32x16 operand wants lane (r, h) = 16 bytes: slice h of pixel / weight row r.  In the plain
+    // [pixel][2 slices] image 16 consecutive lanes would read 16 bytes at a 32-byte stride: only half of the 64 banks, a 2-way
+    // conflict on every ds_read_b128 (PMC: conflict cycles 48 % of LDS-active cycles, with LDS reads at ~75 % of peak before
+    // conflicts).  The two slices of a pixel are therefore stored swapped when bit 3 of its halo column (of its row index,
+    // for weights) is set: 16 consecutive columns then cover every 16-byte slot of the 256-byte bank row exactly once.  The
+    // swizzle costs nothing at run time: it is folded into the DMA source address and into three per-lane base offsets
+    // (one per column offset of a tap).
+    int aoff[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) aoff[d] = ((wave * R_MT) * R_HW + r + d) * 32 + 16 * (h ^ (((r + d) >> 3) & 1));   // + (mt + row offset) * R_HW * 32
+    const int woff = R_A_BYTES + r * 32 + 16 * (h ^ ((r >> 3) & 1));                                       // + (tap * 64 + nt * 32) * 32
 
     // fragment reads run one tap ahead of the MFMAs that use them (see conv_mfma.hip)
     bf16x8_t bfr[2][R_MT], afr[2][R_NT];
 #define RING_FRAGS(boff_, tap_, set_)                                                                              \
     {                                                                                                              \
         const int kh_ = (tap_) / 3, kw_ = (tap_) % 3;                                                               \
-        const int toff_ = ((TR ? kw_ : kh_) * R_HW + (TR ? kh_ : kw_)) * 32;                                        \
-        _Pragma("unroll") for (int mt = 0; mt < R_MT; ++mt) bfr[set_][mt] = ring_frag(smem + (boff_) + aoff + mt * (R_HW * 32) + toff_); \
+        const int drow_ = TR ? kw_ : kh_, dcol_ = TR ? kh_ : kw_;                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < R_MT; ++mt) bfr[set_][mt] = ring_frag(smem + (boff_) + aoff[dcol_] + (mt + drow_) * (R_HW * 32)); \
         _Pragma("unroll") for (int nt = 0; nt < R_NT; ++nt) afr[set_][nt] = ring_frag(smem + (boff_) + woff + ((tap_) * R_BN + nt * 32) * 32); \
     }
     // One chunk: 9 taps x 8 MFMAs.  The R_NDMA requests for the NEXT ring slot (xa_n / ws_n -> tgt_) are spread over the
     // first 7 taps, one or two per tap, each placed behind an MFMA: a wave pays 60-190 cycles of issue time per LDS-DMA
     // instruction, which the matrix pipe covers when they are apart (issued in one burst at the chunk boundary they cost
     // 35-45 % of all wave cycles, measured with the PROF build).
-#define RING_COMPUTE(boff_, tgt_, first_)                                                                                \
+#define RING_COMPUTE(boff_, tgt_, first_)                                                                          \
     RING_FRAGS(boff_, 0, 0)                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     _Pragma("unroll") for (int st = 0; st < 9; ++st) {                                                             \
-        _Pragma("unroll") for (int mt = 0; mt < R_MT; ++mt)                                                         \
-            _Pragma("unroll") for (int nt = 0; nt < R_NT; ++nt)                                                    \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][nt], bfr[st & 1][mt], ((first_) && st == 0) ? zero16 : acc[mt][nt], 0, 0, 0); \
-        if (st + 1 < 9) RING_FRAGS(boff_, st + 1, (st + 1) & 1)                                                    \
-        int ndma_ = 0;                                                                                             \
-        _Pragma("unroll") for (int k = 0; k < R_NDMA; ++k)                                                         \
-            if (k * 7 / R_NDMA == st) { dma_k(k, xa_n, ws_n, tgt_); ++ndma_; }                                     \
+        /* Pinned order (sched_barrier(0) after every instruction group): behind MFMA q comes memory instruction q — the two   \
+           weight fragments and four pixel fragments of the NEXT tap first (their latency hides under the remaining MFMAs, the  \
+           compiler's lgkmcnt before the next tap's first MFMA only covers what that MFMA reads), DMA requests last.  Left to \
+           itself (sched_group_barrier hints included) hipcc issues five MFMAs, then the reads and requests in a clump, then    \
+           waits lgkmcnt(0). */                                                                                    \
+        const int nx_ = (st + 1) & 1, tapn_ = st + 1, khn_ = tapn_ / 3, kwn_ = tapn_ % 3;                           \
+        const int drown_ = TR ? kwn_ : khn_, dcoln_ = TR ? khn_ : kwn_;                                            \
+        int kd_[2] = {-1, -1}, nd_ = 0;                                                                            \
+        _Pragma("unroll") for (int k = 0; k < R_NDMA; ++k) if (k * 7 / R_NDMA == st) kd_[nd_++] = k;               \
         _Pragma("unroll") for (int q_ = 0; q_ < R_MT * R_NT; ++q_) {                                               \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
-            if (q_ < R_MT + R_NT && st + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 \
-            if (q_ >= 2 && q_ < 2 + ndma_) {                                                                       \
-                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                                 \
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                 \
+            const int mt = q_ / R_NT, nt = q_ % R_NT;                                                              \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][nt], bfr[st & 1][mt], ((first_) && st == 0) ? zero16 : acc[mt][nt], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            if (st + 1 < 9) {                                                                                      \
+                if (q_ < R_NT) afr[nx_][q_] = ring_frag(smem + (boff_) + woff + (tapn_ * R_BN + q_ * 32) * 32);    \
+                else if (q_ < R_NT + R_MT) bfr[nx_][q_ - R_NT] = ring_frag(smem + (boff_) + aoff[dcoln_] + (q_ - R_NT + drown_) * (R_HW * 32)); \
             }                                                                                                      \
+            if (q_ >= R_NT + R_MT && kd_[q_ - R_NT - R_MT] >= 0) dma_k(kd_[q_ - R_NT - R_MT], xa_n, ws_n, tgt_);   \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
         }                                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
     }
 
     // finished tile waiting for its stores: 8 channels (16 B) of one pixel per lane and register
