@@ -215,6 +215,28 @@ def test_ring_conv_kernel_is_bit_identical(engine, det_weights, shape, orient):
     assert torch.equal(a, ref)
 
 
+def test_ring_conv_kernel_on_random_page_shapes(engine, det_weights):
+    """Ten seeded random page shapes (1-3 pages, 64-700 px sides: maps from 2x2 to 175x175 pixels, tiles per work-group from a
+    fraction to many, every partial-tile remainder) through the detector with the ring kernel on every layer that has it,
+    against the one-tile-per-work-group kernels."""
+    rng = np.random.default_rng(2025)
+    engine.load_det(det_weights)
+    engine.set_option("conv_big_min", 1)
+    try:
+        for _ in range(10):
+            b, h, w = int(rng.integers(1, 4)), int(rng.integers(64, 700)), int(rng.integers(64, 700))
+            pages = torch.from_numpy(_pages(b, h, w, int(rng.integers(1 << 30)))).cuda()
+            engine.set_option("conv_ring", 0)
+            ref = engine.det_forward(pages).clone()
+            engine.set_option("conv_ring", 1)
+            a = engine.det_forward(pages).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(a, ref), (b, h, w)
+    finally:
+        engine.set_option("conv_ring", 1)
+        engine.set_option("conv_big_min", 1024)
+
+
 @pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901)], ids=lambda s: "b%d_%dx%d" % s)
 def test_channel_blocked_stage0_tensors_are_bit_identical(engine, det_weights, shape):
     """Engine option blocked_layout (an experiment): the stage-0 tensors that only the ring kernel reads and
