@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
         const int rpix_stride = p.res_blk ? 16 : p.res_cstride, rblk_stride = p.res_blk ? hw * 16 : 16;   // as for the output
         const bf16_t* rimg = HAS_RES ? p.res + (size_t)cur.n_img * hw * p.res_cstride + (p.res_blk ? cur.ntile * (R_BN / 16) * (hw * 16) : cur.ntile * R_BN) + 4 * h : nullptr;
         const int ox = cur.oxb + r;
-        uint2 rr[2][R_NT][4];
+        uint2 rr[R_MT][R_NT][4];
         auto load_res = [&](int set, int mt) {
             const int oy = cur.oyb + wave * R_MT + mt;
             const bf16_t* rpix = rimg + ((oy < LH && ox < LW) ? oy * sy + ox * sx : 0) * rpix_stride;
@@ -234,10 +234,12 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
 #pragma unroll
                 for (int g = 0; g < 4; ++g) rr[set][nt][g] = *reinterpret_cast<const uint2*>(rpix + (nt * 2 + (g >> 1)) * rblk_stride + 8 * (g & 1));
         };
-        if constexpr (HAS_RES) load_res(0, 0);
+        if constexpr (HAS_RES) {   // every row requested before the first is used: one exposed memory latency per tile, not one per row
+#pragma unroll
+            for (int mt = 0; mt < R_MT; ++mt) load_res(mt, mt);
+        }
 #pragma unroll
         for (int mt = 0; mt < R_MT; ++mt) {
-            if constexpr (HAS_RES) { if (mt + 1 < R_MT) load_res((mt + 1) & 1, mt + 1); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nt = 0; nt < R_NT; ++nt)
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
                     float v0 = acc[mt][nt][4 * g + 0] + b4.x, v1 = acc[mt][nt][4 * g + 1] + b4.y;
                     float v2 = acc[mt][nt][4 * g + 2] + b4.z, v3 = acc[mt][nt][4 * g + 3] + b4.w;
                     if constexpr (HAS_RES) {
-                        const uint2 rv = rr[mt & 1][nt][g];
+                        const uint2 rv = rr[mt][nt][g];
                         v0 += __uint_as_float(rv.x << 16); v1 += __uint_as_float(rv.x & 0xFFFF0000u);
                         v2 += __uint_as_float(rv.y << 16); v3 += __uint_as_float(rv.y & 0xFFFF0000u);
                     }
