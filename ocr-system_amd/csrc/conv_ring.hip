@@ -214,8 +214,8 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
         }
     };
 
-    // Epilogue of `cur`, one pixel row (mt) at a time so that at most two rows of residual are in registers: the row after the
-    // one being finished is already requested.  Bias comes from LDS (copied once per workgroup): an ordinary global load here
+    // Epilogue of `cur`, one pixel row (mt) at a time; the residual of all four rows is requested before the first is used (the
+    // fragment registers are dead here, so the 64 registers fit).  Bias comes from LDS (copied once per workgroup): an ordinary global load here
     // would make hipcc drain the in-flight DMA at its first use.
     const float* sBias = reinterpret_cast<const float*>(smem + 2 * R_BUF);
     RingTile cur{};
