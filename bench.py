@@ -180,7 +180,7 @@ def main():
                                     "ms_per_step": round(fam_ms, 3), "achieved": round(fam_gf / fam_ms, 2),
                                     "frac": round(fam_gf / fam_ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU port is timed at N = 1 only (13 s of host work)
             try:
                 out["cpu_baseline"] = cpu_baseline(det_w, rec_w, pipe.charset)
             except Exception as e:  # the baseline is informational; never hide the GPU number
