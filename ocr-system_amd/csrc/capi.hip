@@ -17,6 +17,15 @@
     catch (const std::exception& e) { return locr_fail(h, "exception", e.what()); } \
     catch (...) { return locr_fail(h, "exception", "unknown"); }
 
+// every entry that allocates, copies or launches binds the calling thread to the handle's device first: provider threads
+// (asyncio.to_thread workers) start on device 0 whatever device the handle was created on
+#define BIND(h)                                                                                              \
+    do {                                                                                                     \
+        if (!(h)) return 1;                                                                                  \
+        hipError_t _be = hipSetDevice((h)->device);                                                          \
+        if (_be != hipSuccess) return locr_fail((h), "hipSetDevice", hipGetErrorString(_be));                \
+    } while (0)
+
 extern "C" {
 
 const char* lumina_ocr_version(void) { return "lumina-ocr-mi355x 0.1 (gfx950)"; }
@@ -43,6 +52,7 @@ int lumina_ocr_create(int device, lumina_ocr_t** out) {
 
 void lumina_ocr_destroy(lumina_ocr_t* h) {
     if (!h) return;
+    (void)hipSetDevice(h->device);
     for (void* p : h->owned) (void)hipFree(p);
     if (h->ws) (void)hipFree(h->ws);
     if (h->aux) (void)hipFree(h->aux);
@@ -56,7 +66,7 @@ int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value) {
     if (!h || !key) return 1;
     if (!strcmp(key, "det_sub_batch")) h->det_sub_batch = value > 0 ? value : 1;
     else if (!strcmp(key, "rec_sub_batch")) h->rec_sub_batch = value > 0 ? value : 1;
-    else if (!strcmp(key, "keep_taps")) h->keep_taps = value != 0;
+    else if (!strcmp(key, "keep_taps")) h->keep_taps = value < 0 || value > 2 ? 0 : value;
     else if (!strcmp(key, "time_convs")) h->time_convs = value != 0;
     else if (!strcmp(key, "fuse_head")) h->fuse_head = value != 0;
     else if (!strcmp(key, "fuse_mb")) h->fuse_mb = value != 0;
@@ -67,16 +77,19 @@ int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value) {
     else if (!strcmp(key, "conv_big_min")) h->conv_big_min = value >= 0 ? value : 1024;
     else if (!strcmp(key, "ring_orient")) h->ring_orient = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "post_group")) h->post_group = value > 0 ? value : 1;
+    else if (!strcmp(key, "conv2d_variant")) h->conv2d_variant = value < 0 || value > 2 ? 0 : value;
     else return locr_fail(h, "set_option: unknown key", key);
     return 0;
 }
 
 int lumina_ocr_load_det_weights(lumina_ocr_t* h, const void* blob, size_t nbytes) {
     if (!h || !blob) return 1;
+    BIND(h);
     API_TRY return eng_load_det(h, blob, nbytes); API_CATCH(h)
 }
 int lumina_ocr_load_rec_weights(lumina_ocr_t* h, const void* blob, size_t nbytes) {
     if (!h || !blob) return 1;
+    BIND(h);
     API_TRY return eng_load_rec(h, blob, nbytes); API_CATCH(h)
 }
 int lumina_ocr_num_classes(const lumina_ocr_t* h) { return h ? h->num_classes : 0; }
@@ -84,6 +97,7 @@ int lumina_ocr_num_classes(const lumina_ocr_t* h) { return h ? h->num_classes : 
 int lumina_ocr_normalize(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, int hp, int wp, const float scale[3],
                          const float shift[3], int layout_nchw, uint16_t* out_dev, void* stream) {
     if (!h || !img_dev || !out_dev || hp < height || wp < width) return locr_fail(h, "normalize", "bad arguments");
+    BIND(h);
     hipError_t e = normalize_launch(img_dev, out_dev, n, height, width, hp, wp, height, width, scale, shift, layout_nchw, (hipStream_t)stream);
     return e == hipSuccess ? 0 : locr_fail(h, "normalize", hipGetErrorString(e));
 }
@@ -91,6 +105,7 @@ int lumina_ocr_normalize(lumina_ocr_t* h, const uint8_t* img_dev, int n, int hei
 int lumina_ocr_det_forward(lumina_ocr_t* h, const uint8_t* pages_dev, int batch, int height, int width, int hp, int wp, uint16_t* prob_dev,
                            void* stream) {
     if (!h || !pages_dev || !prob_dev) return locr_fail(h, "det_forward", "null argument");
+    BIND(h);
     API_TRY return eng_det_forward(h, pages_dev, batch, height, width, hp, wp, prob_dev, (hipStream_t)stream); API_CATCH(h)
 }
 
@@ -99,6 +114,7 @@ int lumina_ocr_det_postprocess(lumina_ocr_t* h, const uint16_t* prob_dev, int ba
                                int32_t* counts_dev, void* stream) {
     if (!h || !prob_dev || !boxes_dev || !scores_dev || !counts_dev) return locr_fail(h, "det_postprocess", "null argument");
     if (batch <= 0 || max_boxes <= 0 || valid_h > hp || valid_w > wp) return locr_fail(h, "det_postprocess", "bad dimensions");
+    BIND(h);
     API_TRY
     // pages are processed in groups that bound the workspace (~72 MB of labels / row-extreme segments per A4 page)
     const int group = h->post_group;
@@ -120,6 +136,7 @@ int lumina_ocr_det_postprocess(lumina_ocr_t* h, const uint16_t* prob_dev, int ba
 int lumina_ocr_rec_crop(lumina_ocr_t* h, const uint8_t* pages_dev, int batch, int height, int width, const int32_t* quads_dev,
                         const int32_t* page_idx_dev, int n_crops, uint8_t* crops_dev, int32_t* widths_dev, void* stream) {
     if (!h || !pages_dev || !quads_dev || !page_idx_dev || !crops_dev || !widths_dev) return locr_fail(h, "rec_crop", "null argument");
+    BIND(h);
     (void)batch;
     hipError_t e = rec_crop_launch(pages_dev, height, width, quads_dev, page_idx_dev, n_crops, crops_dev, widths_dev, (hipStream_t)stream);
     return e == hipSuccess ? 0 : locr_fail(h, "rec_crop", hipGetErrorString(e));
@@ -128,23 +145,27 @@ int lumina_ocr_rec_crop(lumina_ocr_t* h, const uint8_t* pages_dev, int batch, in
 int lumina_ocr_rec_forward(lumina_ocr_t* h, const uint8_t* crops_dev, const int32_t* widths_dev, int n_crops, int32_t* idx_dev, float* prob_dev,
                            void* stream) {
     if (!h || !crops_dev || !idx_dev || !prob_dev) return locr_fail(h, "rec_forward", "null argument");
+    BIND(h);
     API_TRY return eng_rec_forward(h, crops_dev, widths_dev, n_crops, idx_dev, prob_dev, (hipStream_t)stream); API_CATCH(h)
 }
 
 int lumina_ocr_load_svtr_weights(lumina_ocr_t* h, const void* blob, size_t nbytes) {
     if (!h || !blob) return locr_fail(h, "load_svtr_weights", "null argument");
+    BIND(h);
     API_TRY return eng_load_svtr(h, blob, nbytes); API_CATCH(h)
 }
 
 int lumina_ocr_svtr_forward(lumina_ocr_t* h, const uint8_t* crops_dev, const int32_t* widths_dev, int n_crops, int32_t* idx_dev, float* prob_dev,
                             void* stream) {
     if (!h || !crops_dev || !idx_dev || !prob_dev) return locr_fail(h, "svtr_forward", "null argument");
+    BIND(h);
     API_TRY return eng_svtr_forward(h, crops_dev, widths_dev, n_crops, idx_dev, prob_dev, (hipStream_t)stream); API_CATCH(h)
 }
 
 int lumina_ocr_ctc_decode(lumina_ocr_t* h, const int32_t* idx_dev, const float* prob_dev, int n, int32_t* text_dev, int32_t* len_dev,
                           float* score_dev, void* stream) {
     if (!h || !idx_dev || !prob_dev || !text_dev || !len_dev || !score_dev) return locr_fail(h, "ctc_decode", "null argument");
+    BIND(h);
     if (n <= 0) return 0;
     hipError_t e = ctc_collapse_launch(idx_dev, prob_dev, text_dev, len_dev, score_dev, n, LUMINA_REC_T, (hipStream_t)stream);
     return e == hipSuccess ? 0 : locr_fail(h, "ctc_decode", hipGetErrorString(e));
@@ -154,6 +175,7 @@ int lumina_ocr_conv2d(lumina_ocr_t* h, const uint16_t* x_dev, int n, int height,
                       const float* bias_host, int cout, int ks, int stride, int act, const uint16_t* res_dev, uint16_t* y_dev, void* stream) {
     if (!h || !x_dev || !w_host || !bias_host || !y_dev) return locr_fail(h, "conv2d", "null argument");
     if (cout % 8 != 0) return locr_fail(h, "conv2d", "cout must be a multiple of 8");
+    BIND(h);
     API_TRY
     lumina_ocr* eng = h;
     ConvLayer L;
@@ -169,6 +191,23 @@ int lumina_ocr_conv2d(lumina_ocr_t* h, const uint16_t* x_dev, int n, int height,
     (void)hipMemcpy(dw, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
     (void)hipMemcpy(db, bias.data(), bias.size() * 4, hipMemcpyHostToDevice);
     L.wpk = static_cast<bf16_t*>(dw); L.bias = static_cast<float*>(db);
+    // option conv2d_variant (parity tests): 1 = the LDS-DMA 16x32-tile kernel, 2 = the persistent ring kernel, for the layers
+    // those kernels serve in the detector (3x3 / stride 1, >= 32 input channels in chunks of 16, output channels in tiles of 64)
+    void* dw2 = nullptr;
+    const bool big_ok = ks == 3 && stride == 1 && cin >= 32 && cin % 16 == 0 && cout % 64 == 0 && L.cfg.bn == 64;
+    if (h->conv2d_variant > 0 && !big_ok) { (void)hipFree(dw); (void)hipFree(db); return locr_fail(h, "conv2d", "conv2d_variant 1/2 needs ks 3, stride 1, cin % 16 == 0, cin >= 32, cout % 64 == 0"); }
+    if (h->conv2d_variant > 0) {
+        L.cfg_big = L.cfg; L.cfg_big.nw = 6; L.cfg_big.ck = 16;
+        std::vector<bf16_t> packed2(conv_packed_weight_elems(cout, ks, cin, 64));
+        pack_conv_weights(w_host, cout, ks, cin, 64, 16, packed2.data(), 1);
+        if (hipMalloc(&dw2, packed2.size() * 2) != hipSuccess) { (void)hipFree(dw); (void)hipFree(db); return locr_fail(h, "conv2d", "hipMalloc"); }
+        (void)hipMemcpy(dw2, packed2.data(), packed2.size() * 2, hipMemcpyHostToDevice);
+        L.wpk_big = static_cast<bf16_t*>(dw2);
+        L.force_big = true;
+    }
+    const bool keep_ring = h->conv_ring;
+    if (h->conv2d_variant == 1) h->conv_ring = false;
+    if (h->conv2d_variant == 2) h->conv_ring = true;
     Tensor4 x; x.p = const_cast<bf16_t*>(x_dev); x.n = n; x.h = height; x.w = width; x.c = cin;
     Tensor4 y; y.p = y_dev; y.n = n; y.c = cout;
     y.h = (ks == 3) ? (height - 1) / stride + 1 : height / stride;
@@ -176,7 +215,9 @@ int lumina_ocr_conv2d(lumina_ocr_t* h, const uint16_t* x_dev, int n, int height,
     Tensor4 r; r.p = const_cast<bf16_t*>(res_dev); r.n = n; r.h = y.h; r.w = y.w; r.c = cout;
     int rc = eng_run_conv(eng, L, x, &y, res_dev ? &r : nullptr, 0, OUT_NORMAL, 0, 0, 0, false, (hipStream_t)stream);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    h->conv_ring = keep_ring;
     (void)hipFree(dw); (void)hipFree(db);
+    if (dw2) (void)hipFree(dw2);
     if (rc) return rc;
     return e == hipSuccess ? 0 : locr_fail(h, "conv2d sync", hipGetErrorString(e));
     API_CATCH(h)
@@ -186,6 +227,7 @@ int lumina_ocr_read_tap(lumina_ocr_t* h, const char* name, uint16_t* out_host, s
     if (!h || !name || !dims) return 1;
     auto it = h->taps.find(name);
     if (it == h->taps.end()) return locr_fail(h, "read_tap: unknown tap", name);
+    BIND(h);
     const Tensor4& t = it->second;
     dims[0] = t.n; dims[1] = t.h; dims[2] = t.w; dims[3] = t.c;
     if (!out_host) return 0;
@@ -197,6 +239,7 @@ int lumina_ocr_read_tap(lumina_ocr_t* h, const char* name, uint16_t* out_host, s
 
 int lumina_ocr_conv_timing(lumina_ocr_t* h, double* total_ms, double* total_flops, int* launches) {
     if (!h || !total_ms || !total_flops || !launches) return 1;
+    BIND(h);
     if (hipDeviceSynchronize() != hipSuccess) return locr_fail(h, "conv_timing", "sync failed");
     double ms = 0, fl = 0;
     for (size_t i = 0; i < h->conv_events.size(); ++i) {
@@ -235,6 +278,7 @@ int lumina_ocr_resize_lanczos(lumina_ocr_t* h, const uint8_t* in_dev, int n, int
                               int out_h, int out_w, void* stream) {
     if (!h || !in_dev || !out_dev || n <= 0 || height <= 0 || width <= 0 || out_h <= 0 || out_w <= 0 || channels <= 0)
         return locr_fail(h, "resize_lanczos", "bad arguments");
+    BIND(h);
     API_TRY
     hipStream_t st = (hipStream_t)stream;
     const uint8_t* src = in_dev;
@@ -277,6 +321,7 @@ int lumina_ocr_resize_lanczos(lumina_ocr_t* h, const uint8_t* in_dev, int n, int
 int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, float contrast, float sharpness,
                        uint8_t* tmp_dev, uint8_t* out_dev, void* stream) {
     if (!h || !img_dev || !tmp_dev || !out_dev || n <= 0) return locr_fail(h, "enhance", "bad arguments");
+    BIND(h);
     if (n > h->sums_cap) {
         unsigned long long* s = nullptr;
         if (hipMalloc(reinterpret_cast<void**>(&s), sizeof(unsigned long long) * (size_t)n) != hipSuccess) return locr_fail(h, "enhance", "hipMalloc");
@@ -290,6 +335,7 @@ int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int heigh
 int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, int optimize,
                            uint8_t* out_dev, size_t out_stride, int32_t* sizes_dev, void* stream) {
     if (!h || !pages_dev || !out_dev || !sizes_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "jpeg_encode", "bad arguments");
+    BIND(h);
     API_TRY
     if (eng_ws_reserve(h, jpeg_workspace_bytes(n, height, width))) return 1;
     JpegParams p{};
@@ -302,12 +348,14 @@ int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int
 int lumina_ocr_jpeg_coefficients(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, int16_t* coefs_dev,
                                  void* stream) {
     if (!h || !pages_dev || !coefs_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "jpeg_coefficients", "bad arguments");
+    BIND(h);
     hipError_t e = jpeg_coefficients_launch(pages_dev, n, height, width, quality, coefs_dev, (hipStream_t)stream);
     return e == hipSuccess ? 0 : locr_fail(h, "jpeg_coefficients", hipGetErrorString(e));
 }
 
 int lumina_ocr_conv_timing_detail(lumina_ocr_t* h, char* buf, size_t cap) {
     if (!h || !buf || cap == 0) return 1;
+    BIND(h);
     if (hipDeviceSynchronize() != hipSuccess) return locr_fail(h, "conv_timing_detail", "sync failed");
     std::string out;
     for (size_t i = 0; i < h->conv_events.size(); ++i) {

@@ -40,6 +40,10 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device setting: applied once per (current device, kernel), so that a
+// second handle on another GPU of the same process gets it too (engine.hip)
+hipError_t locr_dyn_lds(const void* kernel, int bytes);
+
 // Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD (round-robin
 // dispatch), so give each XCD label a contiguous range of logical ids (L2 reuse of halos/weights).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -469,12 +469,7 @@ template <int KS, int S, int BN, int CK, int TW, int NW = 4, int DB = 0, int MT 
 hipError_t launch_t(const ConvParams& p, hipStream_t stream) {
     using C = Cfg<KS, S, BN, CK, TW, NW, DB, MT>;
     auto kern = conv_mfma_kernel<KS, S, BN, CK, TW, NW, DB, MT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(kern), C::LDS_BYTES); if (e != hipSuccess) return e; }
     const int grid = p.N * p.tiles_x * p.tiles_y * p.n_tiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, p);
     return hipGetLastError();

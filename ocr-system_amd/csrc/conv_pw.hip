@@ -248,12 +248,7 @@ template <int CIN, int MODE>
 hipError_t launch_pw(const ConvParams& p, long long total_px, hipStream_t stream) {
     auto kern = conv_pw_kernel<CIN, MODE>;
     const size_t lds = (size_t)PW_PX * CIN * 2 + (CIN == 64 ? (size_t)PW_PX * PW_STAGE_PITCH : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PW_PX * CIN * 2 + PW_PX * PW_STAGE_PITCH);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(kern), PW_PX * CIN * 2 + PW_PX * PW_STAGE_PITCH); if (e != hipSuccess) return e; }
     const long long blocks = (total_px + PW_PX - 1) / PW_PX;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p, total_px);
     return hipGetLastError();

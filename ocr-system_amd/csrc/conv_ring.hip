@@ -438,15 +438,9 @@ hipError_t conv_ring_launch(ConvParams p, int orientation, hipStream_t stream) {
                 p.H, p.W, p.Cin, p.Cout, (int)tr, total, w, all / w, 100.0 * hp[0] / all, 100.0 * hp[1] / all, 100.0 * hp[2] / all, 100.0 * hp[3] / all, 100.0 * hp[4] / all);
         return hipGetLastError();
     }
-    static bool attr_done[3] = {false, false, false};
-    const int which = pool ? 2 : (int)tr;
     const void* fn = pool ? reinterpret_cast<const void*>(conv_ring_kernel<0, false, true>)
                           : (tr ? reinterpret_cast<const void*>(conv_ring_kernel<1>) : reinterpret_cast<const void*>(conv_ring_kernel<0>));
-    if (!attr_done[which]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
-        if (e != hipSuccess) return e;
-        attr_done[which] = true;
-    }
+    { hipError_t e = locr_dyn_lds(fn, R_LDS); if (e != hipSuccess) return e; }
     unsigned long long* none = nullptr;
     if (pool) hipLaunchKernelGGL((conv_ring_kernel<0, false, true>), dim3(8 * wg_per_xcd), dim3(256), R_LDS, stream, p, (int)total, per_xcd, wg_per_xcd, none);
     else if (tr) hipLaunchKernelGGL((conv_ring_kernel<1>), dim3(8 * wg_per_xcd), dim3(256), R_LDS, stream, p, (int)total, per_xcd, wg_per_xcd, none);

@@ -28,6 +28,7 @@ struct ConvLayer {
     // second packing for the 16x32-tile / 4x2-register-tile kernel (3x3, stride 1, >= 64 input channels): picked per launch
     // when the grid is large enough to fill the chip with the bigger tiles
     ConvKernelCfg cfg_big{}; bf16_t* wpk_big = nullptr;
+    bool force_big = false;   // conv2d test hook: take the 16x32-tile kernel whatever the grid size / channel count
     bool small_only = false;  // never switch to the 16x32-tile kernel (layers whose maps are only 4-8 rows high)
     bf16_t* fuse_w = nullptr; float fuse_b = 0.f;  // optional fused DBHead tail (see ConvParams)
     float* bias = nullptr;  // device, n_tiles*BN
@@ -82,12 +83,13 @@ struct lumina_ocr {
     bf16_t* zero_block = nullptr;  // 256 B of zeros (out-of-image halo source of the LDS-DMA conv)
     int det_sub_batch = 16, rec_sub_batch = 4096, post_group = 64;
     std::map<std::string, Tensor4> taps;  // last forward's intermediates (debug / parity tests)
-    bool keep_taps = false;
+    int keep_taps = 0;   // 1: every intermediate (switches the fusions that would skip one off); 2: fusions stay on, tap what still exists
     bool fuse_head = true;  // head.convt3 fused into head.convt2's epilogue
     bool fuse_pool = true;  // stem.conv3's epilogue does the 3x3/s2 max pool
     int conv_big_min = 1024;  // 16x32-tile kernels once a full sub-batch gives at least this many work-groups
     bool blocked_layout = false;  // stage-0 activations in channel-blocked layout (experiment)
     bool conv_ring = true;  // persistent ring kernel for the 3x3 / stride-1 layers (conv_ring.hip)
+    int conv2d_variant = 0; // lumina_ocr_conv2d: 0 = the layer's default kernel, 1 = LDS-DMA 16x32 tile, 2 = ring kernel (tests)
     int ring_orient = -1;   // its tile orientation: -1 auto, 0 / 1 forced (tests)
     bool fuse_stem = true;  // stem.conv1 + stem.conv2 in one kernel (the first 32-channel tensor stays in LDS)
     bool fuse_mb = true;    // recogniser blocks: expand + depthwise in one kernel (the expanded tensor stays in LDS)

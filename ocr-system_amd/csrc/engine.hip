@@ -19,6 +19,22 @@ int locr_fail(lumina_ocr* eng, const char* what, const char* detail) {
         if (_e != hipSuccess) return locr_fail(eng, #expr, hipGetErrorString(_e));    \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is per device: remember (device, kernel) pairs, not kernels
+#include <mutex>
+#include <set>
+hipError_t locr_dyn_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, kernel})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({dev, kernel});
+    return e;
+}
+
 // ------------------------------------------------------------------------------ blob
 bool parse_blob(lumina_ocr* eng, const void* blob, size_t n, std::map<std::string, HostBlobTensor>* out) {
     const uint8_t* b = static_cast<const uint8_t*>(blob);
@@ -34,11 +50,18 @@ bool parse_blob(lumina_ocr* eng, const void* blob, size_t n, std::map<std::strin
         std::string name(reinterpret_cast<const char*>(b + off), ln); off += ln;
         HostBlobTensor t;
         t.dtype = b[off]; const int nd = b[off + 1]; off += 2;
+        if (t.dtype > 1 || nd < 1 || nd > 4) { locr_fail(eng, "parse_blob: unknown dtype / rank", name.c_str()); return false; }
         if (off + 4 * (size_t)nd + 8 > n) { locr_fail(eng, "parse_blob", "truncated"); return false; }
-        for (int d = 0; d < nd; ++d) { uint32_t v; memcpy(&v, b + off, 4); off += 4; t.dims.push_back((int)v); }
+        uint64_t count = 1;
+        for (int d = 0; d < nd; ++d) {
+            uint32_t v; memcpy(&v, b + off, 4); off += 4;
+            if (v == 0 || v > (1u << 28) || count * v > (1ull << 34)) { locr_fail(eng, "parse_blob: implausible dimension", name.c_str()); return false; }
+            count *= v; t.dims.push_back((int)v);
+        }
         uint64_t nb; memcpy(&nb, b + off, 8); off += 8;
         off += (16 - off % 16) % 16;
-        if (off + nb > n) { locr_fail(eng, "parse_blob", "truncated data"); return false; }
+        if (off > n || nb > n - off) { locr_fail(eng, "parse_blob", "truncated data"); return false; }   // (off + nb could wrap)
+        if (nb != count * (t.dtype ? 2u : 4u)) { locr_fail(eng, "parse_blob: byte count does not match the dimensions", name.c_str()); return false; }
         t.data = b + off; t.nbytes = (size_t)nb; off += nb;
         (*out)[name] = t;
     }
@@ -246,7 +269,8 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     static const long long big_min_env = getenv("LUMINA_CONV_BIG_MIN") ? atoll(getenv("LUMINA_CONV_BIG_MIN")) : -1;
     const long long big_min = big_min_env >= 0 ? big_min_env : eng->conv_big_min;
     if (out_mode == OUT_POOL && (L.wpk_big == nullptr || L.cfg_big.nw != 6)) return locr_fail(eng, "fused max pool needs the LDS-DMA conv kernel", L.name.c_str());
-    const bool use_big = out_mode == OUT_POOL || (!no_big && !flat && !L.small_only && L.wpk_big != nullptr && big_blocks >= big_min && L.cin >= 64);
+    const bool use_big = out_mode == OUT_POOL || (L.force_big && L.wpk_big != nullptr) || (!no_big && !flat && !L.small_only && L.wpk_big != nullptr && big_blocks >= big_min && L.cin >= 64);
+    if (L.force_big && eng->conv2d_variant == 2 && !conv_ring_supported(L.cfg_big, p)) return locr_fail(eng, "conv2d_variant 2: the ring kernel does not take this layer", L.name.c_str());
     ConvKernelCfg cfg = L.cfg;
     if (use_big) { cfg = L.cfg_big; p.wpk = L.wpk_big; }
     static const bool no_pw = getenv("LUMINA_CONV_NO_PW") != nullptr;
@@ -282,7 +306,7 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
     auto& D = eng->det;
     // stem.conv1 + stem.conv2 fused (the first half-resolution tensor stays in LDS) unless it is wanted as a tap
     ConvLayer& c2 = D["stem.conv2"];
-    const bool fuse_stem = eng->fuse_stem && !eng->keep_taps && c2.cfg.bn == 32 && c2.cfg.ck == 16 && c2.act == ACT_RELU;
+    const bool fuse_stem = eng->fuse_stem && eng->keep_taps != 1 && c2.cfg.bn == 32 && c2.cfg.ck == 16 && c2.act == ACT_RELU;
     Tensor4 t1{};
     if (!fuse_stem || dry) t1 = ws_tensor(eng, B, Hp / 2, Wp / 2, 32);
     Tensor4 t2 = ws_tensor(eng, B, Hp / 2, Wp / 2, 32);
@@ -302,7 +326,7 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
     }
     // stem.conv3 + 3x3/s2 max pool: fused (the 64-channel half-resolution tensor, 93 MB per page, is never written) unless the
     // intermediate is wanted as a tap
-    const bool fuse_pool = eng->fuse_pool && !eng->keep_taps;
+    const bool fuse_pool = eng->fuse_pool && eng->keep_taps != 1;
     Tensor4 t3{};
     if (!fuse_pool || dry) t3 = ws_tensor(eng, B, Hp / 2, Wp / 2, 64);
     Tensor4 x = ws_tensor(eng, B, Hp / 4, Wp / 4, 64);
@@ -323,7 +347,7 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
             const std::string p = "s" + std::to_string(i) + ".b" + std::to_string(j);
             const int stride = (i > 0 && j == 0) ? 2 : 1;
             Tensor4 y = ws_tensor(eng, B, x.h / stride, x.w / stride, chs[i]);
-            const bool blk = i == 0 && eng->blocked_layout && !eng->keep_taps;   // stage-0 tensors that only the ring kernel touches
+            const bool blk = i == 0 && eng->blocked_layout && eng->keep_taps == 0;   // stage-0 tensors that only the ring kernel touches
             y.blk = blk;
             RUN(eng_run_conv(eng, D[p + ".conv0"], x, &y, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st));
             Tensor4 sc = x;
@@ -359,7 +383,7 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
     RUN(eng_run_conv(eng, D["head.conv1"], fuse, &h1, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "head.conv1", h1);
     Tensor4 pm; pm.p = prob; pm.n = B; pm.h = Hp; pm.w = Wp; pm.c = 1;
     if (dry) pm.p = nullptr;
-    if (eng->fuse_head && !eng->keep_taps) {  // DBHead tail in one launch: the 64-channel 1/2-resolution tensor never exists
+    if (eng->fuse_head && eng->keep_taps != 1) {  // DBHead tail in one launch: the 64-channel 1/2-resolution tensor never exists
         RUN(eng_run_conv(eng, D["head.convt2.fused"], h1, &pm, nullptr, 0, OUT_CONVT, 0, 1, 0, false, st));
         return 0;
     }

@@ -177,12 +177,7 @@ hipError_t mbconv_launch(const MbParams& p, int k, int sh, hipStream_t st) {
 #define MB_LAUNCH(K_, SH_, A_)                                                                                                    \
     {                                                                                                                            \
         auto kern = mbconv_kernel<K_, SH_, A_>;                                                                                  \
-        static bool attr = false;                                                                                                \
-        if (!attr) {                                                                                                             \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
-            if (e != hipSuccess) return e;                                                                                       \
-            attr = true;                                                                                                         \
-        }                                                                                                                        \
+        { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(kern), 80 * 1024); if (e != hipSuccess) return e; }                                                                                                                        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);                                                             \
     }
 #define MB_ACT(K_, SH_) { if (p.act == ACT_RELU) MB_LAUNCH(K_, SH_, ACT_RELU) else MB_LAUNCH(K_, SH_, ACT_HSWISH) }

@@ -470,12 +470,7 @@ void pack_ctc_weights(const bf16_t* w, int C, int K, bf16_t* out) {
 hipError_t ctc_fc_argmax_launch(const CtcFcParams& p, hipStream_t st) {
     if (p.K % 16 != 0 || p.K > CT_KMAX) return hipErrorInvalidValue;
     const size_t lds = (size_t)(p.K / 8) * (CT_PLANE_A + CT_BN) * 16;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_fc_argmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(ctc_fc_argmax_kernel), 160 * 1024); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(ctc_fc_argmax_kernel, dim3((p.M + CT_ROWS - 1) / CT_ROWS), dim3(256), lds, st, p);
     return hipGetLastError();
 }

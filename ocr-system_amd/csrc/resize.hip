@@ -394,12 +394,7 @@ void lanczos_coeffs(int in_size, int out_size, int* ksize_out, std::vector<int>*
 
 hipError_t resample_launch(const uint8_t* in, uint8_t* out, const int* bounds_dev, const int* kk_dev, int ksize, int N, int H, int W, int C,
                            int out_len, int axis, const int* bounds_host, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resample_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(resample_h_kernel), 150 * 1024); if (e != hipSuccess) return e; }
     if (axis == 0) {
         const size_t lds = ((size_t)W * C + 8 + 3) / 4 * 4;
         if (lds > 150 * 1024) return hipErrorInvalidValue;

@@ -327,22 +327,12 @@ hipError_t svtr_attention_launch(const bf16_t* qkv, bf16_t* out, int N, int T, i
     size_t lds = (size_t)T * AT_HD * (4 + 2);   // K fp32 + V bf16; the merge buffer aliases K
     if (lds < (size_t)AT_PARTS * 64 * AT_RED * sizeof(float)) lds = (size_t)AT_PARTS * 64 * AT_RED * sizeof(float);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(svtr_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(svtr_attn_kernel), 150 * 1024); if (e != hipSuccess) return e; }
     static const bool valu = getenv("LUMINA_SVTR_ATTN_VALU") != nullptr;   // A/B switch: the fp32 VALU kernel
     if (!valu && T % 32 == 0) {
         const int Tpad = (T + 31) & ~31;
         const size_t lds2 = (size_t)Tpad * MA_KP * 2 + (size_t)32 * (T + 8) * 2;
-        static bool attr2 = false;
-        if (!attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(svtr_attn_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            if (e != hipSuccess) return e;
-            attr2 = true;
-        }
+        { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(svtr_attn_mfma_kernel), 150 * 1024); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(svtr_attn_mfma_kernel, dim3((T + 32 * MA_W - 1) / (32 * MA_W), heads, N), dim3(64 * MA_W), lds2, st, qkv, out, T, heads, gh, gw, local);
         return hipGetLastError();
     }

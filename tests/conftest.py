@@ -29,6 +29,19 @@ def det_weights():
 
 
 @pytest.fixture(scope="session")
+def dense_det_weights():
+    """Seeded weights WITHOUT the hand-set text path: every row of every layer is dense, so the probability map (and every tap)
+    depends on every channel of every layer — what the bit-identity tests of the fused / ring / LDS-DMA kernels need."""
+    from lumina_ocr import arch
+    return arch.make_det_weights(1234, text_path=False)
+
+
+@pytest.fixture(scope="session", params=["text_path", "dense"])
+def any_det_weights(request, det_weights, dense_det_weights):
+    return det_weights if request.param == "text_path" else dense_det_weights
+
+
+@pytest.fixture(scope="session")
 def rec_weights():
     from lumina_ocr import arch
     return arch.make_rec_weights(4321)

@@ -20,6 +20,32 @@ def _dump(name, obj):
         pass
 
 
+# what still exists with every fusion on (engine option keep_taps=2): all of these are compared bit for bit below
+TAPS_FUSED = ["stem.pool", "s0.b0", "s0.b1", "s1.b0", "s1.b1", "s2.b0", "s2.b1", "s3.b0", "s3.b1", "fpn.fuse", "head.conv1"]
+
+
+def _forward_all(engine, pages):
+    """det forward with keep_taps=2 (no fusion is switched off) -> {"prob": bf16 bits, tap name: values}."""
+    engine.set_option("keep_taps", 2)
+    try:
+        prob = engine.det_forward(pages).clone()
+        torch.cuda.synchronize()
+        out = {"prob": prob.view(torch.int16).cpu().numpy()}
+        for name in TAPS_FUSED:
+            out[name] = engine.read_tap(name)
+    finally:
+        engine.set_option("keep_taps", 0)
+    return out
+
+
+def _assert_same(a, b, what=""):
+    for name in a:
+        assert a[name].shape == b[name].shape, (what, name)
+        if not np.array_equal(a[name], b[name]):
+            d = np.argwhere(a[name] != b[name])
+            raise AssertionError("%s: tap %s differs at %d of %d values, first %s" % (what, name, len(d), a[name].size, d[0].tolist()))
+
+
 def _pages(b, h, w, seed):
     return np.stack([synth.synth_page(h, w, seed + i, n_lines=max(3, h // 40))[0] for i in range(b)])
 
@@ -61,9 +87,49 @@ def test_det_forward_taps_and_prob(engine, det_weights, shape):
     assert flips < 1e-2, flips
 
 
-def test_det_sub_batching_is_invisible(engine, det_weights):
+@pytest.mark.parametrize("ring", [0, 1], ids=["lds_dma_tile", "ring"])
+@pytest.mark.parametrize("shape", [(2, 250, 200), (1, 320, 448), (1, 447, 901)], ids=lambda s: "b%d_%dx%d" % s)
+def test_det_taps_vs_oracle_with_the_production_kernels(engine, any_det_weights, shape, ring):
+    """The kernels that run at BASELINE sizes — persistent ring kernel / LDS-DMA 16x32-tile kernel (conv_big_min=1 selects them
+    on these small pages too), fused stem.conv1+conv2, stem.conv3 with the pool in its epilogue, fused DBHead tail — compared
+    with the oracle on EVERY tap that still exists (keep_taps=2 leaves the fusions on).  With the dense weights every channel
+    of every layer reaches the taps: cross-chunk DMA ring, deferred stores, residual path of every channel tile."""
+    from oracle import nets
+    b, h, w = shape
+    pages = _pages(b, h, w, 9)
+    engine.load_det(any_det_weights)
+    engine.set_option("conv_big_min", 1)
+    engine.set_option("conv_ring", ring)
+    engine.set_option("det_sub_batch", 8)
+    engine.conv_timing_detail()
+    engine.set_option("time_convs", 1)
+    try:
+        got = _forward_all(engine, torch.from_numpy(pages).cuda())
+        names = [k for _, k, *_ in engine.conv_timing_detail()]
+    finally:
+        engine.set_option("conv_big_min", 1024)
+        engine.set_option("conv_ring", 1)
+        engine.set_option("time_convs", 0)
+    want = "conv_ring_kernel" if ring else "conv_mfma_kernel<3,1,64,16,32,4,3,4>"
+    assert sum(k.startswith(want) for k in names) >= 10, names
+    assert any(k.startswith("conv_ring_kernel<0,false,true>") or k.endswith(",4,4>") for k in names), names   # pooled stem.conv3
+    taps = {}
+    ref = nets.det_forward(any_det_weights, pages, mode="bf16", taps=taps)
+    stats = {name: close_stats(got[name], taps[name]) for name in TAPS_FUSED}
+    p = arch.bf16_bits_to_f32(got["prob"].view(np.uint16))
+    stats["prob"] = close_stats(p, ref)
+    _dump("parity_det_prod_ring%d_b%d_%dx%d.json" % ((ring,) + shape), stats)
+    for name, s_ in stats.items():
+        if name != "prob":
+            assert got[name].shape == taps[name].shape
+            assert s_["within4"] > 0.90 and s_["mean_abs"] < 0.01 * max(s_["ref_mean_abs"], 1e-3), (name, s_)
+    assert stats["stem.pool"]["within1"] > 0.999 and stats["s0.b0"]["within1"] > 0.99, stats
+    assert stats["prob"]["within4"] > 0.97 and stats["prob"]["max_abs"] < 0.06, stats["prob"]
+
+
+def test_det_sub_batching_is_invisible(engine, any_det_weights):
     pages = torch.from_numpy(_pages(5, 128, 160, 3)).cuda()
-    engine.load_det(det_weights)
+    engine.load_det(any_det_weights)
     engine.set_option("det_sub_batch", 8)
     a = engine.det_forward(pages).clone()
     engine.set_option("det_sub_batch", 2)
@@ -139,10 +205,11 @@ def test_db_postprocess_structured_maps(engine):
     assert total > 5
 
 
-def test_fused_head_equals_unfused(engine, det_weights):
-    """head.convt3 fused into head.convt2's epilogue must give the same bf16 map as the two-launch path."""
+def test_fused_head_equals_unfused(engine, any_det_weights):
+    """head.convt3 fused into head.convt2's epilogue must give the same bf16 map as the two-launch path (dense weights: every
+    one of the 64 channels of head.convt2 feeds the map)."""
     pages = torch.from_numpy(_pages(2, 160, 224, 21)).cuda()
-    engine.load_det(det_weights)
+    engine.load_det(any_det_weights)
     engine.set_option("fuse_head", 1)
     a = engine.det_forward(pages).clone()
     engine.set_option("fuse_head", 0)
@@ -150,101 +217,99 @@ def test_fused_head_equals_unfused(engine, det_weights):
     engine.set_option("fuse_head", 1)
     torch.cuda.synchronize()
     d = (a.float() - b.float()).abs()
-    assert float(d.max()) <= 2.0 ** -8 and float((d > 0).float().mean()) < 1e-3   # same sums, order of the 64-term dot differs
+    # the unfused path rounds the 64-channel half-resolution tensor to bf16 and sums the 64-term dot in another order: a few values
+    # land one bf16 ulp of a probability (<= 2^-8) apart
+    assert float(d.max()) <= 2.0 ** -8 and float((d > 0).float().mean()) < 2e-2, (float(d.max()), float((d > 0).float().mean()))
 
 
 @pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901), (3, 96, 130)], ids=lambda s: "b%d_%dx%d" % s)
-def test_fused_stem_pool_is_bit_identical(engine, det_weights, shape):
+def test_fused_stem_pool_is_bit_identical(engine, any_det_weights, shape):
     """stem.conv3 with the 3x3/s2 max pool in its epilogue (overlapping 16x32 conv tiles, pooled 7x15 per tile, image borders,
     partial tiles) must reproduce the conv + maxpool kernel pair exactly: same conv arithmetic, max picks existing values."""
     b, h, w = shape
     pages = torch.from_numpy(_pages(b, h, w, 33)).cuda()
-    engine.load_det(det_weights)
+    engine.load_det(any_det_weights)
     engine.set_option("fuse_pool", 1)
-    a = engine.det_forward(pages).clone()
+    a = _forward_all(engine, pages)
     engine.set_option("fuse_pool", 0)
-    ref = engine.det_forward(pages).clone()
+    ref = _forward_all(engine, pages)
     engine.set_option("fuse_pool", 1)
-    torch.cuda.synchronize()
-    assert torch.equal(a, ref)
+    _assert_same(a, ref, "fuse_pool")
 
 
 @pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901), (3, 96, 130), (1, 33, 35)], ids=lambda s: "b%d_%dx%d" % s)
-def test_fused_stem_convs_are_bit_identical(engine, det_weights, shape):
+def test_fused_stem_convs_are_bit_identical(engine, any_det_weights, shape):
     """stem.conv1 + stem.conv2 in one kernel (the 32-channel half-resolution tensor only exists as a 10x34-pixel LDS tile per
     work-group) must reproduce the two-kernel path exactly: same bf16 rounding of the intermediate, same chunk->tap summation
     order, conv2's zero padding at the map borders, pages whose size is not a multiple of the tile."""
     b, h, w = shape
     pages = torch.from_numpy(_pages(b, h, w, 35)).cuda()
-    engine.load_det(det_weights)
+    engine.load_det(any_det_weights)
     engine.set_option("fuse_stem", 1)
-    a = engine.det_forward(pages).clone()
+    a = _forward_all(engine, pages)
     engine.set_option("fuse_stem", 0)
-    ref = engine.det_forward(pages).clone()
+    ref = _forward_all(engine, pages)
     engine.set_option("fuse_stem", 1)
-    torch.cuda.synchronize()
-    assert torch.equal(a, ref)
+    _assert_same(a, ref, "fuse_stem")
 
 
 @pytest.mark.parametrize("orient", [-1, 0, 1], ids=["auto", "rows", "transposed"])
 @pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901), (5, 352, 512), (1, 1000, 330)], ids=lambda s: "b%d_%dx%d" % s)
-def test_ring_conv_kernel_is_bit_identical(engine, det_weights, shape, orient):
+def test_ring_conv_kernel_is_bit_identical(engine, any_det_weights, shape, orient):
     """The persistent LDS-DMA ring kernel (conv_ring.hip: tiles strided over resident work-groups, register epilogue, stores
     deferred behind the next tile's DMA, either tile orientation) sums the same products in the same order as the
     one-tile-per-work-group kernel it replaces: the probability maps must be equal bit for bit (residual and plain layers,
     channel-offset output into the FPN concat buffer, partial tiles, one or many tiles per work-group)."""
     b, h, w = shape
     pages = torch.from_numpy(_pages(b, h, w, 41)).cuda()
-    engine.load_det(det_weights)
+    engine.load_det(any_det_weights)
     engine.set_option("conv_big_min", 1)      # the 16x32-tile kernels on every layer that has them, however small the page
-    engine.set_option("time_convs", 1)
     try:
         engine.set_option("conv_ring", 0)
-        ref = engine.det_forward(pages).clone()
+        ref = _forward_all(engine, pages)
         engine.set_option("conv_ring", 1)
         engine.set_option("ring_orient", orient)
-        a = engine.det_forward(pages).clone()
-        torch.cuda.synchronize()
+        engine.conv_timing_detail()
+        engine.set_option("time_convs", 1)
+        a = _forward_all(engine, pages)
         names = [k for _, k, *_ in engine.conv_timing_detail()]
     finally:
         engine.set_option("ring_orient", -1)
         engine.set_option("conv_big_min", 1024)
         engine.set_option("time_convs", 0)
-    torch.cuda.synchronize()
     assert sum(k.startswith("conv_ring_kernel") for k in names) >= 10, names
-    assert torch.equal(a, ref)
+    _assert_same(a, ref, "ring vs one-tile")
 
 
-def test_ring_conv_kernel_on_random_page_shapes(engine, det_weights):
+def test_ring_conv_kernel_on_random_page_shapes(engine, any_det_weights):
     """Ten seeded random page shapes (1-3 pages, 64-700 px sides: maps from 2x2 to 175x175 pixels, tiles per work-group from a
     fraction to many, every partial-tile remainder) through the detector with the ring kernel on every layer that has it,
     against the one-tile-per-work-group kernels."""
     rng = np.random.default_rng(2025)
-    engine.load_det(det_weights)
+    engine.load_det(any_det_weights)
     engine.set_option("conv_big_min", 1)
     try:
         for _ in range(10):
             b, h, w = int(rng.integers(1, 4)), int(rng.integers(64, 700)), int(rng.integers(64, 700))
             pages = torch.from_numpy(_pages(b, h, w, int(rng.integers(1 << 30)))).cuda()
             engine.set_option("conv_ring", 0)
-            ref = engine.det_forward(pages).clone()
+            ref = _forward_all(engine, pages)
             engine.set_option("conv_ring", 1)
-            a = engine.det_forward(pages).clone()
-            torch.cuda.synchronize()
-            assert torch.equal(a, ref), (b, h, w)
+            a = _forward_all(engine, pages)
+            _assert_same(a, ref, "ring, page batch %dx%dx%d" % (b, h, w))
     finally:
         engine.set_option("conv_ring", 1)
         engine.set_option("conv_big_min", 1024)
 
 
 @pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901)], ids=lambda s: "b%d_%dx%d" % s)
-def test_channel_blocked_stage0_tensors_are_bit_identical(engine, det_weights, shape):
+def test_channel_blocked_stage0_tensors_are_bit_identical(engine, any_det_weights, shape):
     """Engine option blocked_layout (an experiment): the stage-0 tensors that only the ring kernel reads and
     writes are stored [n][C/16][H][W][16] instead of NHWC — input halo, residual and output addressing change, the
     arithmetic does not."""
     b, h, w = shape
     pages = torch.from_numpy(_pages(b, h, w, 43)).cuda()
-    engine.load_det(det_weights)
+    engine.load_det(any_det_weights)
     engine.set_option("conv_big_min", 1)
     try:
         engine.set_option("blocked_layout", 0)
@@ -258,11 +323,11 @@ def test_channel_blocked_stage0_tensors_are_bit_identical(engine, det_weights, s
     assert torch.equal(a, ref)
 
 
-def test_page_result_is_independent_of_batch_size(engine, det_weights):
+def test_page_result_is_independent_of_batch_size(engine, any_det_weights):
     """The kernel variant of every layer is chosen from the layer geometry and the configured sub-batch, never from the number
     of pages in the call (different tilings sum the same products in a different order): one page alone == the same page in a batch."""
     pages = torch.from_numpy(_pages(5, 352, 512, 77)).cuda()
-    engine.load_det(det_weights)
+    engine.load_det(any_det_weights)
     batch = engine.det_forward(pages).clone()
     single = engine.det_forward(pages[2:3]).clone()
     torch.cuda.synchronize()
