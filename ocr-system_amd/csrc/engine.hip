@@ -269,7 +269,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     static const long long big_min_env = getenv("LUMINA_CONV_BIG_MIN") ? atoll(getenv("LUMINA_CONV_BIG_MIN")) : -1;
     const long long big_min = big_min_env >= 0 ? big_min_env : eng->conv_big_min;
     if (out_mode == OUT_POOL && (L.wpk_big == nullptr || L.cfg_big.nw != 6)) return locr_fail(eng, "fused max pool needs the LDS-DMA conv kernel", L.name.c_str());
-    const bool use_big = out_mode == OUT_POOL || (L.force_big && L.wpk_big != nullptr) || (!no_big && !flat && !L.small_only && L.wpk_big != nullptr && big_blocks >= big_min && L.cin >= 64);
+    const bool use_big = out_mode == OUT_POOL || (L.force_big && L.wpk_big != nullptr) || (!no_big && !flat && !L.small_only && L.wpk_big != nullptr && big_blocks >= big_min);
     if (L.force_big && eng->conv2d_variant == 2 && !conv_ring_supported(L.cfg_big, p)) return locr_fail(eng, "conv2d_variant 2: the ring kernel does not take this layer", L.name.c_str());
     ConvKernelCfg cfg = L.cfg;
     if (use_big) { cfg = L.cfg_big; p.wpk = L.wpk_big; }
