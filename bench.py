@@ -6,6 +6,8 @@ Workload (BASELINE.json configs[3], the configuration the metric is quoted on; i
   already resident in HBM): LANCZOS resize to the reference's 2000-px cap (1414x2000) + contrast/sharpness
   -> DBNet-R18vd (zero-padded to 1440x2016) -> DB post-process -> crops -> CRNN-MV3 + CTC -> decoded strings.
   N GPUs: one process per GPU, 64 pages per rank per step (weak scaling), one RCCL all-gather of the boxes per step.
+  `python bench.py --gpus N` starts the N ranks itself (a launcher process that never touches the GPU); under
+  `python -m torch.distributed.run` (RANK set) it is one of the ranks.
 Weights are seeded random-init (no checkpoints exist offline); data is synthetic (rendered text + noise).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
@@ -26,6 +28,7 @@ sys.path.insert(0, str(ROOT))
 PAGES_PER_RANK = 64
 A4_H, A4_W = 2339, 1654
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PMC_FILE = "r02_pmc_hbm.json"          # {"source_sha16": {file: sha}, "kernels": {name: {"hbm_bytes_per_launch": ...}}} (tools/pmc_to_json.py)
 
 
 def make_pages(torch, n, seed, device):
@@ -62,6 +65,59 @@ def cpu_baseline(det_w, rec_w, charset, n_pages=6):
                       % (n_pages, sum(len(o["texts"]) for o in out), dt)}
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with no RANK in the environment: this process becomes the launcher.  It never touches the GPU
+    (no torch.cuda call, not even an import of torch): it starts N fresh child processes of this file, one rank per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, waits for them and exits non-zero if any of them did.
+    Rank 0 inherits stdout and prints the one JSON line.  (Under `python -m torch.distributed.run` RANK is set and this is skipped.)"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LUMINA_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for r, p in enumerate(procs):
+        c = p.wait()
+        if c != 0:
+            print("bench.py: rank %d exited with code %d" % (r, c), file=sys.stderr)
+            rc = rc or (c if c > 0 else 1)
+    return rc
+
+
+class DryPipeline:
+    """--dry-engine (CPU rehearsal of the N-rank path, tests/test_bench_launcher.py): same submission structure and the same
+    PageGather calls as OcrPipeline, with seeded fake recogniser outputs instead of the HIP engine.  Never used for a number."""
+
+    def __init__(self, torch, rank, gather, pages):
+        import numpy as np
+        self.torch, self.np, self.rank, self.gather, self.pages = torch, np, rank, gather, pages
+
+    def run_many(self, batches):
+        np, torch = self.np, self.torch
+        for step, _ in enumerate(batches):
+            rng = np.random.default_rng(1000 * self.rank + step)
+            counts = rng.integers(0, 5, self.pages).astype(np.int32)
+            n = int(counts.sum())
+            if self.gather is None:      # single process: no collective at all
+                from types import SimpleNamespace
+                yield [SimpleNamespace(texts=["x"] * int(c)) for c in counts], None
+                continue
+            self.gather.begin(counts)
+            quads = torch.from_numpy(rng.integers(0, 2000, (n, 8)).astype(np.int32))
+            text = torch.full((n, 80), -1, dtype=torch.int32)
+            text[:, :3] = torch.from_numpy(rng.integers(1, 90, (n, 3)).astype(np.int32))
+            length = torch.full((n,), 3, dtype=torch.int32)
+            sc = torch.from_numpy(rng.random(n, dtype=np.float32))
+            yield self.gather.finish(self.gather.submit(counts, quads, sc, text, length, sc)), None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,51 +126,71 @@ def main():
     ap.add_argument("--pages", type=int, default=PAGES_PER_RANK, help="pages per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--det-sub-batch", type=int, default=16)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal, only with --dry-engine")
+    ap.add_argument("--dry-engine", action="store_true", help="no GPU, fake recogniser outputs: rehearses launcher + gather on CPU")
     args = ap.parse_args()
+    if args.backend == "gloo" and not args.dry_engine:
+        ap.error("--backend gloo is the CPU rehearsal of the multi-rank path and needs --dry-engine (the engine has no CPU path)")
+
+    # N > 1 without a launcher: become the launcher (before anything touches the GPU)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
     from lumina_ocr import arch
-    from lumina_ocr.dist import all_gather_pages
-    from lumina_ocr.engine import Engine
-    from lumina_ocr.pipeline import OcrPipeline
+    from lumina_ocr.dist import PageGather
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    distributed = world > 1 or "RANK" in os.environ   # under torchrun the RCCL path runs even at world size 1
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: reporting n_gpus=%d (the ranks that actually ran)" % (args.gpus, world, world), file=sys.stderr)
+    distributed = world > 1 or "RANK" in os.environ   # under a launcher the collective path runs even at world size 1
+    dry = args.dry_engine
+    device = torch.device("cpu") if dry else torch.device("cuda", local_rank)
+    if not dry:
+        torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dry:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=device)
+    ranks_seen = dist.get_world_size() if distributed else 1
 
-    det_w, rec_w = arch.make_det_weights(1234), arch.make_rec_weights(4321)
-    eng = Engine(local_rank)            # raises if liblumina_ocr.so is missing: there is no fallback path
-    eng.load_det(det_w)
-    eng.load_rec(rec_w)
-    eng.set_option("det_sub_batch", args.det_sub_batch)
-    pipe = OcrPipeline(eng, post=arch.TEXT_PATH_POST)
-    pages = make_pages(torch, args.pages, 2024 + 1000 * rank, device)
-
-    side = torch.cuda.Stream(device) if distributed else None   # result gather runs beside the next step's detection kernels
-
-    def gather(dets):
-        return all_gather_pages(dets, pipe.charset, device=device, pages_per_rank=args.pages, stream=side) if distributed else dets
+    charset = arch.ctc_charset()
+    side = torch.cuda.Stream(device) if (distributed and not dry) else None   # result gather runs beside the next step's detection kernels
+    gather = PageGather(charset, args.pages, device=device, stream=side) if distributed else None
+    det_w = rec_w = eng = None
+    if dry:
+        pipe, pages = DryPipeline(torch, rank, gather, args.pages), None
+    else:
+        from lumina_ocr.engine import Engine
+        from lumina_ocr.pipeline import OcrPipeline
+        det_w, rec_w = arch.make_det_weights(1234), arch.make_rec_weights(4321)
+        eng = Engine(local_rank)            # raises if liblumina_ocr.so is missing: there is no fallback path
+        eng.load_det(det_w)
+        eng.load_rec(rec_w)
+        eng.set_option("det_sub_batch", args.det_sub_batch)
+        pipe = OcrPipeline(eng, charset=charset, post=arch.TEXT_PATH_POST, gather=gather)
+        pages = make_pages(torch, args.pages, 2024 + 1000 * rank, device)
 
     def run_steps(k):
-        """k steps through OcrPipeline.run_many: step i's host-side string decode (and result gather) overlaps the device
-        work of step i+1; every step's work, including the last decode, is finished when this returns."""
+        """k steps through run_many: step i's host-side string decode (multi-GPU: its result gather, on a side stream) overlaps
+        the device work of step i+1; every step's work, including the last decode / gather, is finished when this returns."""
         dets = None
         for d, _ in pipe.run_many(pages for _ in range(k)):
-            dets = gather(d)
+            dets = d
         return dets
 
     def fence():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     dets = run_steps(args.warmup)
     fence()
@@ -127,30 +203,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_lines = int(dets.counts.sum()) if hasattr(dets, "counts") else sum(len(d.texts) for d in dets)
+    n_pages_last = len(dets)
 
-    # ---- roofline: HIP events on the launch stream around every conv_mfma launch of one extra step ----
-    eng.set_option("time_convs", 1)
-    pipe.run(pages)
-    rows = eng.conv_timing_detail()          # (layer, kernel instantiation, ms, GFLOP, algorithmic MB) per launch
-    eng.set_option("time_convs", 0)
-    by_kernel = {}
-    for _, kern, ms, gf, mb in rows:
-        a = by_kernel.setdefault(kern, [0, 0.0, 0.0, 0.0])
-        a[0] += 1; a[1] += ms; a[2] += gf; a[3] += mb
-    dom = max(by_kernel, key=lambda k: by_kernel[k][1])
-    dn, dms, dgf, dmb = by_kernel[dom]
-    fam_ms = sum(a[1] for a in by_kernel.values()); fam_gf = sum(a[2] for a in by_kernel.values())
-    achieved = dgf / dms if dms > 0 else 0.0   # GFLOP/ms == TFLOP/s
-    traffic = None
-    try:  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/r01_pmc_hbm.json, 16-page det forward)
-        pmc = json.loads((ROOT / "profiles" / "r01_pmc_hbm.json").read_text())
-        want = dom.replace(" ", "")
-        for name, v in pmc.get("all", pmc).items():     # rocprofv3 prints "conv_ring_kernel<1, false>(ConvParams, ...)"
-            flat = name.replace(" ", "").replace(",false,false>", ">")
-            if want in flat:
-                traffic = v.get("hbm_bytes_per_launch")
-    except Exception:
-        pass
+    roofline = None
+    if not dry:
+        roofline = measure_roofline(eng, pipe, pages)
 
     if rank == 0:
         hp, wp = 2016, 1440
@@ -170,25 +227,71 @@ def main():
             "data": "synthetic (rendered text pages + noise, seeded); weights random-init (seeded), no checkpoints offline",
             "config": {"workload": "end-to-end det+rec, batch=64 A4@200DPI pages per GPU (BASELINE configs[3])",
                        "pages_per_gpu": args.pages, "global_batch": args.pages * world, "page_px": [A4_H, A4_W],
-                       "det_input_px": [hp, wp], "lines_last_step": n_lines, "parallelism": "pages sharded dp%d, 1 all-gather/step" % world},
-            "roofline": {"bound": "mfma", "kernel": dom, "launches_per_step": dn, "avg_launch_us": round(dms / dn * 1e3, 1),
-                         "flop_per_launch": dgf / dn * 1e9, "algorithmic_bytes_per_launch": dmb / dn * 1e6,
-                         "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "mean HBM bytes/launch of this kernel in a 16-page det forward (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm.json); bench launches cover 16-page sub-batches too",
-                         "family": {"kernel": "all conv launches (conv_ring_kernel + conv_mfma_kernel instantiations + conv_pw_kernel)", "launches_per_step": len(rows),
-                                    "ms_per_step": round(fam_ms, 3), "achieved": round(fam_gf / fam_ms, 2),
-                                    "frac": round(fam_gf / fam_ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}},
+                       "det_input_px": [hp, wp], "lines_last_step": n_lines, "pages_gathered_last_step": n_pages_last,
+                       "parallelism": "pages sharded dp%d, 1 all-gather/step" % world,
+                       "ranks": ranks_seen, "collective_backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if distributed else None,
+                       "input": "pages pre-decoded (uint8 RGB) and resident in HBM when the timed region starts",
+                       "outside_timed_region": "image decode, host->device copy, JPEG hand-off of the processed page (3.7 ms per 64 pages on the device)"},
+            "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:   # the CPU port is timed at N = 1 only (13 s of host work)
+        if dry:
+            out["data"] = "DRY ENGINE (CPU rehearsal of the launcher and the gather; not a measurement)"
+            out["value"] = None
+        if not args.no_cpu_baseline and world == 1 and not dry:   # the CPU port is timed at N = 1 only (13 s of host work)
             try:
-                out["cpu_baseline"] = cpu_baseline(det_w, rec_w, pipe.charset)
+                out["cpu_baseline"] = cpu_baseline(det_w, rec_w, charset)
             except Exception as e:  # the baseline is informational; never hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "pages/sec", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %s" % e}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _sha16(path):
+    import hashlib
+    return hashlib.sha256(Path(path).read_bytes()).hexdigest()[:16]
+
+
+def measure_roofline(eng, pipe, pages):
+    """HIP events on the launch stream around every conv launch of one extra step (outside the timed region)."""
+    eng.set_option("time_convs", 1)
+    pipe.finish(pipe.submit_recognize(*pipe.submit_detect(pages)))
+    rows = eng.conv_timing_detail()          # (layer, kernel instantiation, ms, GFLOP, algorithmic MB) per launch
+    eng.set_option("time_convs", 0)
+    by_kernel = {}
+    for _, kern, ms, gf, mb in rows:
+        a = by_kernel.setdefault(kern, [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += gf; a[3] += mb
+    dom = max(by_kernel, key=lambda k: by_kernel[k][1])
+    dn, dms, dgf, dmb = by_kernel[dom]
+    fam_ms = sum(a[1] for a in by_kernel.values()); fam_gf = sum(a[2] for a in by_kernel.values())
+    achieved = dgf / dms if dms > 0 else 0.0   # GFLOP/ms == TFLOP/s
+    # HBM bytes per launch: separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950 correction), committed
+    # under profiles/ together with the hash of the kernel sources they were taken on; a stale file yields null, never an old number
+    traffic, note = None, "no PMC file for the current kernel sources"
+    try:
+        pmc = json.loads((ROOT / "profiles" / PMC_FILE).read_text())
+        srcs = pmc.get("source_sha16", {})
+        cur = {k: _sha16(ROOT / "ocr-system_amd" / "csrc" / k) for k in srcs}
+        if srcs and cur == srcs:
+            want = dom.replace(" ", "")
+            for name, v in pmc["kernels"].items():
+                flat = name.replace(" ", "").replace(",false,false>", ">")
+                if want in flat:
+                    traffic = v.get("hbm_bytes_per_launch")
+                    note = "mean HBM bytes/launch of this kernel in a 16-page det forward (profiles/%s); bench launches cover 16-page sub-batches too" % PMC_FILE
+        else:
+            note = "profiles/%s was collected on other kernel sources than the ones running: not reported" % PMC_FILE
+    except Exception:
+        pass
+    return {"bound": "mfma", "kernel": dom, "launches_per_step": dn, "avg_launch_us": round(dms / dn * 1e3, 1),
+            "flop_per_launch": dgf / dn * 1e9, "algorithmic_bytes_per_launch": dmb / dn * 1e6,
+            "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
+            "family": {"kernel": "all conv launches (conv_ring_kernel + conv_mfma_kernel instantiations + conv_pw_kernel)", "launches_per_step": len(rows),
+                       "ms_per_step": round(fam_ms, 3), "achieved": round(fam_gf / fam_ms, 2),
+                       "frac": round(fam_gf / fam_ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}}
 
 
 if __name__ == "__main__":

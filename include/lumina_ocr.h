@@ -93,6 +93,21 @@ int lumina_ocr_resize_lanczos(lumina_ocr_t* h, const uint8_t* in_dev, int n, int
 int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, float contrast, float sharpness,
                        uint8_t* tmp_dev, uint8_t* out_dev, void* stream);
 
+/* deskew (image_preprocessing.py:372-460; on by default in the provider: backend/config.py:85, ocr_service.py:412-417): Canny(50, 150)
+ * -> Hough line segments (threshold 100, min length 100, max gap 10) -> median of the segment angles folded into [-45, 45] ->
+ * unchanged below 0.5 / above 45 degrees -> cubic affine warp about (W / 2, H / 2) with replicated borders.  The reference does
+ * this with OpenCV (absent offline: "parity unpinned"); the arithmetic is defined by oracle/csrc/deskew_oracle.c and reproduced
+ * bit for bit.  pages_dev uint8 [n,H,W,3]; out_dev (same shape, may be NULL: estimate only) receives the rotated page or a copy;
+ * rot_dev double [n][3] = sin, cos of the angle and a flag (0 no line found, 1 below 0.5 degrees, 2 above 45 degrees, 3 rotated);
+ * info_dev int32 [n][2] = segments found, Hough peaks walked.  Optional parity hooks (NULL to skip): edges_dev uint8 [n,H,W]
+ * (0 / 255), segs_dev int32 [n][512][8][4] (x1, y1, x2, y2) with nsegs_dev int32 [n][512] segments per peak slot.  Asynchronous. */
+int lumina_ocr_deskew(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, uint8_t* out_dev, double* rot_dev,
+                      int32_t* info_dev, uint8_t* edges_dev, int32_t* segs_dev, int32_t* nsegs_dev, void* stream);
+/* The warp alone, for given (sin, cos, flag) triples: cv2.getRotationMatrix2D((w // 2, h // 2), angle, 1.0) + cv2.warpAffine(...,
+ * flags=INTER_CUBIC, borderMode=BORDER_REPLICATE) (image_preprocessing.py:446-454) in OpenCV's fixed-point arithmetic. */
+int lumina_ocr_deskew_warp(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, const double* rot_dev, uint8_t* out_dev,
+                           void* stream);
+
 /* Second recogniser family (BASELINE configs[4]: SVTR): same slot and the same outputs as lumina_ocr_load_rec_weights /
  * lumina_ocr_rec_forward (the `rec` model of the engine call, ocr_service_paddleocr_backup.py:232-238, :285), with an SVTR-Tiny
  * backbone (patch embedding, local / global mixing blocks, CTC head) instead of CRNN.  Blob: LOCW with the `svtr.*` tensors of
@@ -100,6 +115,7 @@ int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int heigh
 int lumina_ocr_load_svtr_weights(lumina_ocr_t* h, const void* blob, size_t nbytes);
 int lumina_ocr_svtr_forward(lumina_ocr_t* h, const uint8_t* crops_dev, const int32_t* widths_dev, int n_crops, int32_t* idx_dev, float* prob_dev,
                             void* stream);
+int lumina_ocr_svtr_num_classes(const lumina_ocr_t* h);   /* class count of the loaded SVTR head (lumina_ocr_num_classes: the CRNN's) */
 
 /* JPEG hand-off of the processed page: replaces image.save(buffer, format='JPEG', quality=q, optimize=True) inside
  * ImagePreprocessor.compress_for_azure (backend/utils/image_preprocessing.py:526-538; the bytes become OCROutput.processed_image_bytes,

@@ -5,6 +5,7 @@
 
 #include "../../include/lumina_ocr.h"
 #include "dbpost.h"
+#include "deskew.h"
 #include "engine.h"
 #include "ops.h"
 #include "resize.h"
@@ -352,6 +353,60 @@ int lumina_ocr_jpeg_coefficients(lumina_ocr_t* h, const uint8_t* pages_dev, int 
     hipError_t e = jpeg_coefficients_launch(pages_dev, n, height, width, quality, coefs_dev, (hipStream_t)stream);
     return e == hipSuccess ? 0 : locr_fail(h, "jpeg_coefficients", hipGetErrorString(e));
 }
+
+static int deskew_tables(lumina_ocr* h) {
+    if (h->dk_trig && h->dk_wtab) return 0;
+    float trig[360];
+    std::vector<short> wtab(32 * 32 * 16);
+    deskew_trig_table(trig);
+    deskew_weight_table(wtab.data());
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, sizeof(trig)) != hipSuccess || hipMalloc(&b, wtab.size() * 2) != hipSuccess) return locr_fail(h, "deskew", "hipMalloc tables");
+    (void)hipMemcpy(a, trig, sizeof(trig), hipMemcpyHostToDevice);
+    (void)hipMemcpy(b, wtab.data(), wtab.size() * 2, hipMemcpyHostToDevice);
+    h->owned.push_back(a); h->owned.push_back(b);
+    h->dk_trig = static_cast<float*>(a); h->dk_wtab = static_cast<short*>(b);
+    return 0;
+}
+
+int lumina_ocr_deskew(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, uint8_t* out_dev, double* rot_dev, int32_t* info_dev,
+                      uint8_t* edges_dev, int32_t* segs_dev, int32_t* nsegs_dev, void* stream) {
+    if (!h || !pages_dev || !rot_dev || !info_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "deskew", "bad arguments");
+    if ((segs_dev == nullptr) != (nsegs_dev == nullptr)) return locr_fail(h, "deskew", "segs_dev and nsegs_dev go together");
+    BIND(h);
+    API_TRY
+    if (deskew_tables(h)) return 1;
+    // pages are processed in groups that bound the workspace (~16 bytes per pixel + the accumulators)
+    const int group = h->post_group;
+    for (int b0 = 0; b0 < n; b0 += group) {
+        const int nb = n - b0 < group ? n - b0 : group;
+        if (eng_ws_reserve(h, deskew_workspace_bytes(nb, height, width))) return 1;
+        const size_t px = (size_t)height * width;
+        DeskewParams p{};
+        p.rgb = pages_dev + (size_t)b0 * px * 3; p.out = out_dev ? out_dev + (size_t)b0 * px * 3 : nullptr;
+        p.B = nb; p.H = height; p.W = width; p.trig = h->dk_trig; p.wtab = h->dk_wtab;
+        p.rot = rot_dev + (size_t)b0 * 3; p.info = info_dev + (size_t)b0 * 2;
+        p.edges_out = edges_dev ? edges_dev + (size_t)b0 * px : nullptr;
+        p.segs_out = segs_dev ? segs_dev + (size_t)b0 * DESKEW_MAX_PEAKS * DESKEW_SEG_PER_PEAK * 4 : nullptr;
+        p.nsegs_out = nsegs_dev ? nsegs_dev + (size_t)b0 * DESKEW_MAX_PEAKS : nullptr;
+        hipError_t e = deskew_launch(p, h->ws, (hipStream_t)stream);
+        if (e != hipSuccess) return locr_fail(h, "deskew", hipGetErrorString(e));
+    }
+    return 0;
+    API_CATCH(h)
+}
+
+int lumina_ocr_deskew_warp(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, const double* rot_dev, uint8_t* out_dev, void* stream) {
+    if (!h || !pages_dev || !rot_dev || !out_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "deskew_warp", "bad arguments");
+    BIND(h);
+    API_TRY
+    if (deskew_tables(h)) return 1;
+    hipError_t e = deskew_warp_launch(pages_dev, out_dev, rot_dev, h->dk_wtab, n, height, width, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : locr_fail(h, "deskew_warp", hipGetErrorString(e));
+    API_CATCH(h)
+}
+
+int lumina_ocr_svtr_num_classes(const lumina_ocr_t* h) { return h ? h->svtr.num_classes : 0; }
 
 int lumina_ocr_conv_timing_detail(lumina_ocr_t* h, char* buf, size_t cap) {
     if (!h || !buf || cap == 0) return 1;

@@ -103,6 +103,7 @@ struct lumina_ocr {
     std::map<std::pair<int, int>, Coeffs> coeff_cache;  // (in, out) -> device tables
     uint8_t* aux = nullptr; size_t aux_cap = 0;         // resize intermediate
     unsigned long long* sums = nullptr; int sums_cap = 0;
+    float* dk_trig = nullptr; short* dk_wtab = nullptr;   // de-skew tables (deskew.h), uploaded at first use
 };
 
 int locr_fail(lumina_ocr* eng, const char* what, const char* detail);

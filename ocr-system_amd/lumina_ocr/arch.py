@@ -183,6 +183,47 @@ def ctc_charset(num_classes: int = 6625) -> List[str]:
     return ["\x00"] + chars[:n_chars] + [" "]
 
 
+class TextDecoder:
+    """class ids [n, T] (-1 padded) + lengths [n] -> strings.  Dictionaries whose symbols are single code points (every PP-OCR
+    key file) decode vectorised through utf-32; multi-code-point symbols fall back to a join per line."""
+
+    def __init__(self, charset: List[str]):
+        self.charset = list(charset)
+        self.single = all(len(c) == 1 for c in self.charset)
+        self._cp = np.array([ord(c) for c in self.charset], dtype="<u4") if self.single else None
+
+    def decode(self, ids: np.ndarray, lens: np.ndarray) -> List[str]:
+        if len(ids) == 0:
+            return []
+        if self.single:
+            cps = self._cp[np.maximum(ids, 0)]
+            return [cps[i, : lens[i]].tobytes().decode("utf-32-le") for i in range(len(ids))]
+        return ["".join(self.charset[k] for k in ids[i, : lens[i]]) for i in range(len(ids))]
+
+
+def load_charset(path, use_space_char: bool = True) -> List[str]:
+    """Dictionary FILE -> class list.  Format = PP-OCR key files (ppocr_keys_v1.txt, devanagari_dict.txt ...): UTF-8, one symbol
+    per line, no header.  Class 0 is the CTC blank, the file's symbols follow in file order, a space is appended last
+    (PP-OCR `use_space_char`).  The provider checks len(result) against the recogniser head's class count."""
+    from pathlib import Path
+    lines = Path(path).read_text(encoding="utf-8").split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    syms = [ln.rstrip("\r") for ln in lines]
+    if any(len(s) == 0 for s in syms):
+        raise ValueError("dictionary %s holds an empty line" % path)
+    if len(set(syms)) != len(syms):
+        raise ValueError("dictionary %s holds duplicate symbols" % path)
+    return ["\x00"] + syms + ([" "] if use_space_char and " " not in syms else [])
+
+
+def save_charset(path, charset: List[str]) -> None:
+    """Inverse of load_charset for a class list that starts with the blank and ends with the space."""
+    from pathlib import Path
+    assert charset[0] == "\x00" and charset[-1] == " "
+    Path(path).write_text("".join(c + "\n" for c in charset[1:-1]), encoding="utf-8")
+
+
 def devanagari_charset() -> List[str]:
     """blank + Devanagari block + digits/latin punctuation + space (config 5; build's own list)."""
     chars = [chr(c) for c in range(0x0900, 0x0980)] + [chr(c) for c in range(0x21, 0x7F) if not chr(c).isalpha()]

@@ -69,6 +69,9 @@ def load_library() -> ctypes.CDLL:
         "lumina_ocr_jpeg_coefficients": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
         "lumina_ocr_load_svtr_weights": (i32, [vp, vp, sz]),
         "lumina_ocr_svtr_forward": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+        "lumina_ocr_svtr_num_classes": (i32, [vp]),
+        "lumina_ocr_deskew": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+        "lumina_ocr_deskew_warp": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     }
     missing = []
     for name, (res, args) in sig.items():
@@ -90,7 +93,7 @@ EXPORTED_SYMBOLS = [
     "lumina_ocr_det_forward", "lumina_ocr_det_postprocess", "lumina_ocr_rec_crop", "lumina_ocr_rec_forward",
     "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing", "lumina_ocr_conv_timing_detail",
     "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients",
-    "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward",
+    "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward", "lumina_ocr_svtr_num_classes", "lumina_ocr_deskew", "lumina_ocr_deskew_warp",
 ]
 
 
@@ -119,8 +122,8 @@ class Engine:
         if rc != 0:
             msg = self.lib.lumina_ocr_last_error(h).decode() if h else "create failed"
             raise EngineUnavailable(msg)
-        self.num_classes = 0
-        self.det_loaded = self.rec_loaded = False
+        self.num_classes = self.svtr_num_classes = 0
+        self.det_loaded = self.rec_loaded = self.svtr_loaded = False
 
     # -- plumbing -------------------------------------------------------------------------
     def close(self):
@@ -188,6 +191,7 @@ class Engine:
         buf = ctypes.create_string_buffer(bytes(blob), len(blob))
         self._chk(self.lib.lumina_ocr_load_svtr_weights(self._h, ctypes.cast(buf, ctypes.c_void_p), len(blob)))
         self.svtr_loaded = True
+        self.svtr_num_classes = self.lib.lumina_ocr_svtr_num_classes(self._h)
 
     # -- hot path -------------------------------------------------------------------------
     def normalize(self, img, hp: int, wp: int, scale, shift, nchw: bool = False):
@@ -308,6 +312,41 @@ class Engine:
         out = torch.empty((n, out_h, out_w, c), dtype=torch.uint8, device=img.device)
         self._chk(self.lib.lumina_ocr_resize_lanczos(self._h, _ptr(img), n, h, w, c, _ptr(out), out_h, out_w, self._stream()))
         return out
+
+    # -- de-skew (image_preprocessing.py:372-460) ---------------------------------------------
+    def deskew(self, pages, debug: bool = False, estimate_only: bool = False):
+        """uint8 [n,H,W,3] device -> (de-skewed pages (or None), rot float64 [n,3] device = sin, cos, flag).  Asynchronous: the
+        rotation of each page is estimated and applied on the device.  debug=True also returns (info int32 [n,2] = segments,
+        peaks; Canny edge maps uint8 [n,H,W]; segments int32 [n,512,8,4]; segments per peak slot int32 [n,512])."""
+        torch = _torch()
+        n, h, w, c = pages.shape
+        assert c == 3 and pages.dtype == torch.uint8 and pages.is_contiguous()
+        out = None if estimate_only else torch.empty_like(pages)
+        rot = torch.empty((n, 3), dtype=torch.float64, device=pages.device)
+        info = torch.empty((n, 2), dtype=torch.int32, device=pages.device)
+        edges = segs = nsegs = None
+        if debug:
+            edges = torch.empty((n, h, w), dtype=torch.uint8, device=pages.device)
+            segs = torch.zeros((n, 512, 8, 4), dtype=torch.int32, device=pages.device)
+            nsegs = torch.zeros((n, 512), dtype=torch.int32, device=pages.device)
+        self._chk(self.lib.lumina_ocr_deskew(self._h, _ptr(pages), n, h, w, _ptr(out), _ptr(rot), _ptr(info), _ptr(edges), _ptr(segs), _ptr(nsegs),
+                                             self._stream()))
+        return (out, rot, info, edges, segs, nsegs) if debug else (out, rot)
+
+    def deskew_warp(self, pages, rot):
+        """The cubic warp alone for given (sin, cos, flag) triples (float64 [n,3] device); flag != 3 copies the page."""
+        torch = _torch()
+        n, h, w, _ = pages.shape
+        out = torch.empty_like(pages)
+        self._chk(self.lib.lumina_ocr_deskew_warp(self._h, _ptr(pages), n, h, w, _ptr(rot), _ptr(out), self._stream()))
+        return out
+
+    @staticmethod
+    def skew_degrees(rot) -> list:
+        """rot (device or host [n,3]) -> the angle the reference's deskew() returns next to the image (:441-447, :460):
+        the detected angle when the page was rotated or left alone below 0.5 degrees, 0.0 otherwise.  Synchronises."""
+        r = rot.cpu().numpy() if hasattr(rot, "cpu") else np.asarray(rot)
+        return [float(np.degrees(np.arctan2(s, c))) if int(f) in (1, 3) else 0.0 for s, c, f in r]
 
     def enhance(self, img, contrast: float = 1.2, sharpness: float = 1.1):
         torch = _torch()

@@ -43,26 +43,33 @@ class _Pending:
     processed: object
     host: Optional[list] = None
     event: Optional[object] = None
+    gathered: Optional[object] = None   # multi-GPU: handle of dist.PageGather.submit (the batch's results of ALL ranks)
 
 
 class OcrPipeline:
     def __init__(self, engine: Engine, charset: Optional[List[str]] = None, max_dimension: int = 2000, post: Optional[dict] = None,
-                 recognizer: str = "crnn"):
-        """recognizer: "crnn" (CRNN-MobileNetV3 + BiLSTM, engine.load_rec) or "svtr" (SVTR-Tiny, engine.load_svtr)."""
+                 recognizer: str = "crnn", gather=None):
+        """recognizer: "crnn" (CRNN-MobileNetV3 + BiLSTM, engine.load_rec) or "svtr" (SVTR, engine.load_svtr).
+        gather: a dist.PageGather — multi-GPU runs: every batch's results are all-gathered from the device tensors and
+        finish() returns a GatheredPages over the pages of ALL ranks instead of this rank's PageDetections."""
         assert recognizer in ("crnn", "svtr")
         self.recognizer = recognizer
+        self.gather = gather
         self.eng = engine
         self.charset = charset or arch.ctc_charset(engine.num_classes or 6625)
-        self._codepoints = np.array([ord(c) for c in self.charset], dtype="<u4")   # class id -> code point (vectorised decode)
+        self._decoder = arch.TextDecoder(self.charset)   # class ids -> strings (vectorised for single-code-point dictionaries)
         self.max_dimension = max_dimension
         self.post = dict(arch.DEFAULT_POST if post is None else post)
 
     # ---- stages -------------------------------------------------------------------------
-    def preprocess(self, pages, enhance: bool = True):
-        """uint8 [B,H,W,3] device -> processed uint8 [B,H',W',3] (image_preprocessing.py:559-628 without deskew/JPEG)."""
+    def preprocess(self, pages, enhance: bool = True, deskew: bool = False):
+        """uint8 [B,H,W,3] device -> processed uint8 [B,H',W',3]: the reference's order (image_preprocessing.py:559-628 /
+        :191-242): resize -> [deskew] -> contrast 1.2 -> sharpness 1.1 (JPEG hand-off is the provider's)."""
         b, h, w, _ = pages.shape
         nw, nh = get_optimal_size(w, h, self.max_dimension)
         x = pages if (nw, nh) == (w, h) else self.eng.resize_lanczos(pages, nh, nw)
+        if deskew:
+            x, self.last_skew_angles = self.eng.deskew(x)
         return self.eng.enhance(x, 1.2, 1.1) if enhance else x
 
     def detect(self, processed):
@@ -74,9 +81,9 @@ class OcrPipeline:
         return self.finish(self.submit_recognize(processed, boxes, scores, counts))[0]
 
     # ---- split submission: lets the host-side decode of batch k overlap the device work of batch k+1 ----------------
-    def submit_detect(self, pages, enhance: bool = True):
-        """Enqueue resize/enhance + DBNet + DB post-process; no host synchronisation. -> handle for submit_recognize."""
-        processed = self.preprocess(pages, enhance)
+    def submit_detect(self, pages, enhance: bool = True, deskew: bool = False):
+        """Enqueue resize/[deskew]/enhance + DBNet + DB post-process; no host synchronisation. -> handle for submit_recognize."""
+        processed = self.preprocess(pages, enhance, deskew)
         return (processed,) + tuple(self.detect(processed))
 
     def submit_recognize(self, processed, boxes, scores, counts) -> "_Pending":
@@ -86,7 +93,12 @@ class OcrPipeline:
         counts_h = counts.cpu().numpy()  # the one host sync of the pipeline
         n = int(counts_h.sum())
         pend = _Pending(b=b, w=w, h=h, counts_h=counts_h, n=n, processed=processed)
+        if self.gather is not None:
+            self.gather.begin(counts_h)          # capacity all-reduce runs beside the recogniser
         if n == 0:
+            if self.gather is not None:          # every rank takes part in the collective, with or without lines
+                e = lambda *shape, dt=torch.int32: torch.empty(shape, dtype=dt, device=boxes.device)
+                pend.gathered = self.gather.submit(counts_h, e(0, 8), e(0, dt=torch.float32), e(0, 80), e(0), e(0, dt=torch.float32))
             return pend
         # the valid (page, slot) pairs are known on the host (counts): one small index upload + three gathers, instead of boolean-mask
         # indexing (each of those runs a nonzero kernel and synchronises to learn its output size)
@@ -100,6 +112,9 @@ class OcrPipeline:
         crops, widths = self.eng.rec_crop(processed, quads, page_idx)
         idx, prob = (self.eng.svtr_forward if self.recognizer == "svtr" else self.eng.rec_forward)(crops, widths)
         text, length, score = self.eng.ctc_decode(idx, prob)
+        if self.gather is not None:
+            pend.gathered = self.gather.submit(counts_h, quads, det_sc, text, length, score)
+            return pend
         pend.host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True) for t in (text, length, score, quads, det_sc)]
         pend.event = torch.cuda.Event()
         pend.event.record(torch.cuda.current_stream(processed.device))
@@ -108,32 +123,34 @@ class OcrPipeline:
     def finish(self, pend: "_Pending") -> Tuple[List[PageDetections], "object"]:
         """Wait for the pending batch's copies and build the per-page results (string decode on the host)."""
         b, w, h = pend.b, pend.w, pend.h
+        if pend.gathered is not None:
+            return self.gather.finish(pend.gathered), pend.processed
         if pend.n == 0:
             return [PageDetections(np.zeros((0, 8), np.int32), [], np.zeros(0, np.float32), np.zeros(0, np.float32), w, h) for _ in range(b)], pend.processed
         pend.event.synchronize()
         text_h, len_h, score_h, quads_h, det_h = (t.numpy() for t in pend.host)
-        cps = self._codepoints[np.maximum(text_h, 0)]          # [n, 80] uint32 code points; one utf-32 decode per line
+        all_texts = self._decoder.decode(text_h, len_h)
         out, off = [], 0
         for p in range(b):
             c = int(pend.counts_h[p])
-            texts = [cps[i, : len_h[i]].tobytes().decode("utf-32-le") for i in range(off, off + c)]
+            texts = all_texts[off:off + c]
             out.append(PageDetections(quads_h[off:off + c], texts, score_h[off:off + c], det_h[off:off + c], w, h,
                                       text_h[off:off + c], len_h[off:off + c]))
             off += c
         return out, pend.processed
 
-    def run_many(self, batches, enhance: bool = True):
+    def run_many(self, batches, enhance: bool = True, deskew: bool = False):
         """Generator over batches: yields (detections, processed) per batch, in order, with batch k's host decode running
         while the device works on batch k+1's detection half."""
         pending = None
         for pages in batches:
-            h = self.submit_detect(pages, enhance)
+            h = self.submit_detect(pages, enhance, deskew)
             if pending is not None:
                 yield self.finish(pending)
             pending = self.submit_recognize(*h)
         if pending is not None:
             yield self.finish(pending)
 
-    def run(self, pages, enhance: bool = True) -> Tuple[List[PageDetections], "object"]:
+    def run(self, pages, enhance: bool = True, deskew: bool = False) -> Tuple[List[PageDetections], "object"]:
         """-> (per-page detections, processed pages on device)."""
-        return self.finish(self.submit_recognize(*self.submit_detect(pages, enhance)))
+        return self.finish(self.submit_recognize(*self.submit_detect(pages, enhance, deskew)))

@@ -101,39 +101,83 @@ class OCRService:
         self._engine_lock = threading.Lock()
         self._semaphore = threading.Semaphore(1)
         self.max_dimension = int(os.environ.get("OCR_MAX_IMAGE_DIMENSION", 2000))
+        # settings.OCR_APPLY_DESKEW (/root/reference/backend/config.py:85, default True; used at ocr_service.py:150, :412-417)
+        self.apply_deskew = os.environ.get("OCR_APPLY_DESKEW", "true").lower() not in ("0", "false", "no")
         self._device = int(os.environ.get("LUMINA_OCR_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self._det_weights = os.environ.get("LUMINA_OCR_DET_WEIGHTS", "")
         self._rec_weights = os.environ.get("LUMINA_OCR_REC_WEIGHTS", "")
         self._recognizer = os.environ.get("LUMINA_OCR_RECOGNIZER", "crnn")        # "crnn" | "svtr" (BASELINE configs[4] family)
         self._svtr_weights = os.environ.get("LUMINA_OCR_SVTR_WEIGHTS", "")
+        self._rec_dict = os.environ.get("LUMINA_OCR_REC_DICT", "")               # dictionary file: one symbol per line (PP-OCR key-file format)
+        self._allow_synthetic = os.environ.get("LUMINA_OCR_ALLOW_SYNTHETIC", "") == "1"
         self._weights_kind = "unloaded"
         self._pre = ImagePreprocessor(self.max_dimension)
         self._initialized = True
 
     # ---- engine management (reference: _ensure_client_initialized :166-207) ----
     def _ensure_engine(self) -> None:
+        """Builds the engine once.  Like the reference without Azure credentials (:175-195), a provider without its weights is
+        an ERROR, returned as data by the callers: seeded synthetic networks are only used when LUMINA_OCR_ALLOW_SYNTHETIC=1
+        says so (tests, demos, the benchmark), never silently."""
         if self._pipeline is not None:
             return
         with self._engine_lock:
             if self._pipeline is not None:
                 return
+            import torch
             from ..engine import Engine
             from ..pipeline import OcrPipeline
+            svtr = self._recognizer == "svtr"
+            have_files = bool(self._det_weights) and bool(self._svtr_weights if svtr else self._rec_weights)
+            if not have_files and not self._allow_synthetic:
+                missing = [k for k, v in (("LUMINA_OCR_DET_WEIGHTS", self._det_weights),
+                                          ("LUMINA_OCR_SVTR_WEIGHTS" if svtr else "LUMINA_OCR_REC_WEIGHTS", self._svtr_weights if svtr else self._rec_weights)) if not v]
+                raise RuntimeError("OCR weights not configured: set %s (LOCW blobs) and LUMINA_OCR_REC_DICT, or LUMINA_OCR_ALLOW_SYNTHETIC=1 "
+                                   "for seeded synthetic networks" % " and ".join(missing))
+            if have_files and not self._rec_dict:
+                raise RuntimeError("LUMINA_OCR_REC_DICT (the dictionary file the recogniser was trained with) is required with weight files")
             eng = Engine(self._device)  # raises EngineUnavailable without the HIP library / a GPU
-            if self._det_weights and self._rec_weights:
-                eng.load_det(Path(self._det_weights).read_bytes())
-                eng.load_rec(Path(self._rec_weights).read_bytes())
-                self._weights_kind = "files"
-            else:  # no trained weights ship offline: deterministic seeded networks
-                eng.load_det(arch.make_det_weights())
-                eng.load_rec(arch.make_rec_weights())
-                self._weights_kind = "seeded-synthetic"
+            try:
+                with torch.cuda.device(self._device):
+                    if have_files:
+                        eng.load_det(Path(self._det_weights).read_bytes())
+                        if svtr:
+                            eng.load_svtr(Path(self._svtr_weights).read_bytes())
+                        else:
+                            eng.load_rec(Path(self._rec_weights).read_bytes())
+                        charset = arch.load_charset(self._rec_dict)
+                        kind, post = "files", arch.DEFAULT_POST
+                    else:  # no trained weights ship offline (SURVEY.md §0.5): deterministic seeded networks, on request only
+                        logger.warning("OCR provider is running SEEDED SYNTHETIC networks (LUMINA_OCR_ALLOW_SYNTHETIC=1): recognised text is not meaningful")
+                        eng.load_det(arch.make_det_weights())
+                        charset = arch.load_charset(self._rec_dict) if self._rec_dict else arch.ctc_charset()
+                        if svtr:
+                            eng.load_svtr(arch.make_svtr_weights(num_classes=len(charset)))
+                        else:
+                            eng.load_rec(arch.make_rec_weights(num_classes=len(charset)))
+                        kind, post = "seeded-synthetic", arch.TEXT_PATH_POST
+                    n_cls = eng.svtr_num_classes if svtr else eng.num_classes
+                    if len(charset) != n_cls:
+                        raise RuntimeError("dictionary has %d classes (blank + symbols + space) but the %s head has %d"
+                                           % (len(charset), "SVTR" if svtr else "CRNN", n_cls))
+                    pipeline = OcrPipeline(eng, charset=charset, max_dimension=self.max_dimension, post=post, recognizer=self._recognizer)
+            except Exception:
+                eng.close()
+                raise
+            self._weights_kind = kind
             self._engine = eng
             self._pre._engine = eng
-            post = arch.TEXT_PATH_POST if self._weights_kind == "seeded-synthetic" else arch.DEFAULT_POST
-            if self._recognizer == "svtr":
-                eng.load_svtr(Path(self._svtr_weights).read_bytes() if self._svtr_weights else arch.make_svtr_weights())
-            self._pipeline = OcrPipeline(eng, max_dimension=self.max_dimension, post=post, recognizer=self._recognizer)
+            self._pipeline = pipeline
+
+    def _device_ctx(self):
+        """Binds the calling thread (possibly an asyncio.to_thread worker, which starts on device 0) to the engine's GPU."""
+        import torch
+        return torch.cuda.device(self._device)
+
+    def _upload(self, arr: np.ndarray):
+        """Host uint8 [n,H,W,3] -> the engine's device (worker threads start on device 0 whatever LUMINA_OCR_DEVICE says)."""
+        import torch
+        return torch.from_numpy(arr).to(torch.device("cuda", self._device))
 
     # ---- single image (:398-475) ----
     def _prepare(self, image: Image.Image) -> np.ndarray:
@@ -166,8 +210,9 @@ class OCRService:
                 import torch
                 self._ensure_engine()
                 arr = self._prepare(image)
-                dets, processed = self._pipeline.run(torch.from_numpy(arr.copy())[None].cuda())
-                jpeg = self._pre.compress_for_azure_device(processed)[0]   # processed_image_bytes: encoded on the device
+                with self._device_ctx():
+                    dets, processed = self._pipeline.run(self._upload(arr.copy()[None]), deskew=self.apply_deskew)
+                    jpeg = self._pre.compress_for_azure_device(processed)[0]   # processed_image_bytes: encoded on the device
                 return self._finish_page(dets[0], jpeg, tuple(processed.shape[1:3]), page_number, original_size, t0)
             except Exception as e:  # errors are data (:464-475)
                 logger.error("OCR failed: %s", e)
@@ -199,8 +244,9 @@ class OCRService:
                     import torch
                     self._ensure_engine()
                     batch = np.stack([self._prepare(images[i]) for i in idxs])
-                    dets, processed = self._pipeline.run(torch.from_numpy(batch).cuda())
-                    jpegs = self._pre.compress_for_azure_device(processed)
+                    with self._device_ctx():
+                        dets, processed = self._pipeline.run(self._upload(batch), deskew=self.apply_deskew)
+                        jpegs = self._pre.compress_for_azure_device(processed)
                     for j, i in enumerate(idxs):
                         out[i] = self._finish_page(dets[j], jpegs[j], tuple(processed.shape[1:3]), first_page_number + i, images[i].size, t0)
                 except Exception as e:
@@ -263,7 +309,7 @@ class OCRService:
     # ---- status (:759-795) ----
     def get_status(self) -> Dict[str, Any]:
         st = {"client_initialized": self._pipeline is not None, "model_id": "dbnet-r18vd+crnn-mv3", "max_dimension": self.max_dimension,
-              "device": self._device, "weights": self._weights_kind, "engine": "Lumina MI355X det+rec (HIP, gfx950)"}
+              "device": self._device, "weights": self._weights_kind, "recognizer": self._recognizer, "apply_deskew": self.apply_deskew, "engine": "Lumina MI355X det+rec (HIP, gfx950)"}
         if self._engine is not None:
             st["engine_version"] = self._engine.version()
             st["num_classes"] = self._engine.num_classes

@@ -1,0 +1,341 @@
+/* ORACLE (test infrastructure only; never linked into the product).
+ *
+ * Plain-C, sequential restatement of the reference's de-skew step,
+ *   /root/reference/backend/utils/image_preprocessing.py:372-460  (ImagePreprocessor.deskew), called by default from
+ *   /root/reference/backend/services/ocr_service.py:412-417 (settings.OCR_APPLY_DESKEW, backend/config.py:85):
+ *     gray -> cv2.Canny(gray, 50, 150, apertureSize=3) -> cv2.HoughLinesP(edges, 1, pi/180, threshold=100, minLineLength=100,
+ *     maxLineGap=10) -> angle of every segment folded once into [-45, 45] -> median -> skip when |angle| < 0.5 or > 45 ->
+ *     cv2.getRotationMatrix2D((w//2, h//2), angle, 1.0) -> cv2.warpAffine(INTER_CUBIC, BORDER_REPLICATE).
+ * The arithmetic lives in OpenCV (opencv-python; unpinned in the reference, requirements.txt lists it without a version), a
+ * third-party dependency ABSENT from /root/reference and from this image (cv2 is not importable): the reference itself
+ * degrades to a no-op without it (:383-385).  There are no fixtures of its output either => "PARITY UNPINNED".
+ * What follows restates OpenCV's published algorithms (4.x: imgproc/src/color_rgb, canny.cpp, hough.cpp, imgwarp.cpp) and
+ * DEFINES the result the HIP path (ocr-system_amd/csrc/deskew.hip) must reproduce bit for bit:
+ *
+ *  1. gray = (4899 R + 9617 G + 1868 B + 8192) >> 14                      (cvtColor ..2GRAY, 14-bit fixed point)
+ *  2. Canny, L1 norm: Sobel 3x3 dx, dy with replicated borders; mag = |dx| + |dy| (0 outside the image); a pixel with mag > 50 is
+ *     kept when it is a maximum along its gradient direction, quantised with tan(22.5 deg) = 13573 / 2^15:
+ *       |dy| 2^15 < |dx| 13573            : mag >  left       and mag >= right
+ *       |dy| 2^15 > |dx| (13573 + 2^16)   : mag >  above      and mag >= below
+ *       otherwise (s = -1 when dx, dy differ in sign, else 1) : mag > (above, x - s) and mag > (below, x + s)
+ *     kept pixels with mag > 150 are strong; the edge map is every kept pixel 8-connected to a strong one (hysteresis).
+ *  3. Line segments.  OpenCV's HoughLinesP is the *progressive probabilistic* transform: it visits edge pixels in a random
+ *     order drawn from cv::RNG and its output depends on that order.  A data-parallel device cannot reproduce a sequential
+ *     random walk, and without OpenCV there is nothing to compare it with, so this step is DEFINED deterministically with the
+ *     same parameters and the same geometry conventions (documented deviation):
+ *       a. full accumulator, as HoughLinesStandard: for every edge pixel (x, y) and n in [0, 180):
+ *          r = rint(x * cosf_n + y * sinf_n) + (numrho - 1) / 2,  numrho = 2 (W + H) + 1, float tables (float)(cos(n pi/180));
+ *       b. peaks: accum >= 100 that are local maxima as in HoughLinesStandard ( > left, >= right in rho; > previous, >= next
+ *          angle; outside the table = 0); of these, the ones with at least vcut votes are visited, vcut = the smallest value
+ *          >= 100 for which at most 512 peaks qualify (a page of text has ~10^5 bins above the threshold: like the progressive
+ *          transform, which looks at the strongest direction of each pixel it draws, only the dominant lines are walked; a tie
+ *          group is never split, so the set does not depend on any visiting order);
+ *       c. each peak's line is walked over the whole image in HoughLinesP's 16.16 fixed point (x-major when |sin| > |cos|):
+ *          maximal runs of edge pixels with gaps <= 10, kept when |dx| >= 100 or |dy| >= 100 (at most 8 per peak, in walk
+ *          order); end points ordered as HoughLinesP orders them (first = the end reached in direction (dx0, dy0)):
+ *          x-major: left -> right; y-major: bottom -> top when cos > 0, top -> bottom otherwise.
+ *  4. angle: each segment vector (vx, vy) is folded as the reference folds its angle — once, +90 when below -45, -90 when
+ *     above 45 degrees, here as exact quarter turns of the integer vector — and the median is taken by exact order (tan of the
+ *     folded vector, reduced by its gcd, as a correctly rounded double).  The rotation uses the median DIRECTION: (cos, sin) = (fx, fy) / |f|
+ *     (two middle vectors for an even count: the normalised sum of their unit vectors = the mean of the two angles), so the
+ *     whole chain needs only + - * / sqrt, which are correctly rounded on the host and on the GPU alike (the reference goes
+ *     through degrees and cos / sin of libm; the difference is ~1e-16 relative, far below the 2^-10 grid of step 5).
+ *     flag: 0 no segment; 1 |angle| < 0.5 deg (|sin| < sin 0.5): unchanged; 2 |angle| > 45: unchanged; 3 rotate.
+ *  5. warpAffine(INTER_CUBIC, BORDER_REPLICATE) in OpenCV's fixed point: M = getRotationMatrix2D((W/2, H/2), angle, 1),
+ *     inverted as warpAffine inverts it; X = (rint((M1 y + M2) 1024) + 16 + rint(M0 x 1024)) >> 5 (same for Y), source
+ *     pixel (X >> 5, Y >> 5), 32 x 32 sub-pixel phases; 4x4 bicubic weights (A = -0.75) as 15-bit shorts, the products of the
+ *     float 1-D tables, their sum forced to 2^15 on the largest (smallest) of the central 2x2 weights;
+ *     dst = saturate_u8((sum + 2^14) >> 15), source coordinates clamped to the image.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define DK_LOW 50
+#define DK_HIGH 150
+#define DK_TG22 13573
+#define DK_NANGLE 180
+#define DK_THRESH 100
+#define DK_MINLEN 100
+#define DK_MAXGAP 10
+#define DK_MAX_PEAKS 512
+#define DK_MAX_VOTES 8192   /* > the longest possible line of a page (votes are clamped into the histogram) */
+#define DK_SEG_PER_PEAK 8
+#define DK_SIN_HALF_DEG 0.008726535498373935   /* sin(0.5 deg) */
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* steps 1 + 2 -> map: 0 kept (weak), 1 not an edge, 2 strong;  then hysteresis -> edges 0 / 255 */
+void oracle_deskew_canny(const uint8_t* rgb, int H, int W, uint8_t* edges) {
+    const size_t n = (size_t)H * W;
+    uint8_t* gray = (uint8_t*)malloc(n);
+    int16_t* dx = (int16_t*)malloc(n * 2);
+    int16_t* dy = (int16_t*)malloc(n * 2);
+    int32_t* mag = (int32_t*)malloc(n * 4);
+    uint8_t* map = (uint8_t*)malloc(n);
+    for (size_t i = 0; i < n; ++i) gray[i] = (uint8_t)((4899 * rgb[3 * i] + 9617 * rgb[3 * i + 1] + 1868 * rgb[3 * i + 2] + 8192) >> 14);
+#define G(y, x) ((int)gray[(size_t)clampi(y, 0, H - 1) * W + clampi(x, 0, W - 1)])
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int gx = (G(y - 1, x + 1) + 2 * G(y, x + 1) + G(y + 1, x + 1)) - (G(y - 1, x - 1) + 2 * G(y, x - 1) + G(y + 1, x - 1));
+            const int gy = (G(y + 1, x - 1) + 2 * G(y + 1, x) + G(y + 1, x + 1)) - (G(y - 1, x - 1) + 2 * G(y - 1, x) + G(y - 1, x + 1));
+            dx[(size_t)y * W + x] = (int16_t)gx; dy[(size_t)y * W + x] = (int16_t)gy;
+            mag[(size_t)y * W + x] = abs(gx) + abs(gy);
+        }
+#undef G
+#define M(y, x) (((y) < 0 || (y) >= H || (x) < 0 || (x) >= W) ? 0 : mag[(size_t)(y) * W + (x)])
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const size_t i = (size_t)y * W + x;
+            const int m = mag[i];
+            uint8_t v = 1;
+            if (m > DK_LOW) {
+                const int xs = dx[i], ys = dy[i];
+                const int ax = abs(xs), ay = abs(ys) << 15;
+                const int tg22x = ax * DK_TG22;
+                int keep = 0;
+                if (ay < tg22x) keep = m > M(y, x - 1) && m >= M(y, x + 1);
+                else {
+                    const int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x) keep = m > M(y - 1, x) && m >= M(y + 1, x);
+                    else {
+                        const int s = (xs ^ ys) < 0 ? -1 : 1;
+                        keep = m > M(y - 1, x - s) && m > M(y + 1, x + s);
+                    }
+                }
+                if (keep) v = m > DK_HIGH ? 2 : 0;
+            }
+            map[i] = v;
+        }
+#undef M
+    /* hysteresis: flood from the strong pixels through the kept ones, 8-connected */
+    int32_t* stack = (int32_t*)malloc(n * 4);
+    size_t sp = 0;
+    memset(edges, 0, n);
+    for (size_t i = 0; i < n; ++i) if (map[i] == 2) { edges[i] = 255; stack[sp++] = (int32_t)i; }
+    while (sp) {
+        const int32_t i = stack[--sp];
+        const int y = i / W, x = i % W;
+        for (int oy = -1; oy <= 1; ++oy)
+            for (int ox = -1; ox <= 1; ++ox) {
+                const int yy = y + oy, xx = x + ox;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                const size_t j = (size_t)yy * W + xx;
+                if (map[j] == 0 && !edges[j]) { edges[j] = 255; stack[sp++] = (int32_t)j; }
+            }
+    }
+    free(gray); free(dx); free(dy); free(mag); free(map); free(stack);
+}
+
+/* float trig tables of HoughLinesP: (float)(cos((double)n * theta)), theta = pi / 180 as the reference passes it (np.pi / 180) */
+void oracle_deskew_trig(float* tab /* [180][2] */) {
+    const double theta = 3.141592653589793 / 180;
+    for (int n = 0; n < DK_NANGLE; ++n) { tab[2 * n] = (float)cos((double)n * theta); tab[2 * n + 1] = (float)sin((double)n * theta); }
+}
+
+/* step 3 -> segments (x1, y1, x2, y2) in HoughLinesP's end-point order; returns their number; *n_peaks = peaks visited */
+int oracle_deskew_segments(const uint8_t* edges, int H, int W, int32_t* segs, int max_segs, int32_t* n_peaks, int32_t* accum_out /* nullable [180][numrho] */) {
+    const int numrho = 2 * (W + H) + 1, half = (numrho - 1) / 2;
+    float tab[2 * DK_NANGLE];
+    oracle_deskew_trig(tab);
+    int32_t* acc = (int32_t*)calloc((size_t)DK_NANGLE * numrho, 4);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            if (!edges[(size_t)y * W + x]) continue;
+            for (int n = 0; n < DK_NANGLE; ++n) {
+                const float a = (float)x * tab[2 * n], b = (float)y * tab[2 * n + 1];
+                const float sum = a + b;
+                acc[(size_t)n * numrho + (int)lrintf(sum) + half]++;
+            }
+        }
+    if (accum_out) memcpy(accum_out, acc, (size_t)DK_NANGLE * numrho * 4);
+#define A(n, r) (((n) < 0 || (n) >= DK_NANGLE || (r) < 0 || (r) >= numrho) ? 0 : acc[(size_t)(n) * numrho + (r)])
+#define IS_PEAK(n, r, v) ((v) >= DK_THRESH && (v) > A(n, (r) - 1) && (v) >= A(n, (r) + 1) && (v) > A((n) - 1, r) && (v) >= A((n) + 1, r))
+    /* the DK_MAX_PEAKS strongest: vote histogram of the peaks -> cut value vcut and how many peaks with exactly vcut votes fit */
+    int32_t* hist = (int32_t*)calloc(DK_MAX_VOTES, 4);
+    for (int n = 0; n < DK_NANGLE; ++n)
+        for (int r = 0; r < numrho; ++r) {
+            const int v = A(n, r);
+            if (IS_PEAK(n, r, v)) hist[v < DK_MAX_VOTES ? v : DK_MAX_VOTES - 1]++;
+        }
+    int vcut = DK_MAX_VOTES, above = 0;   /* smallest v >= DK_THRESH with count(votes >= v) <= DK_MAX_PEAKS */
+    for (int v = DK_MAX_VOTES - 1; v >= DK_THRESH; --v) {
+        if (above + hist[v] > DK_MAX_PEAKS) break;
+        above += hist[v];
+        vcut = v;
+    }
+    free(hist);
+    int ns = 0, np = 0;
+    for (int n = 0; n < DK_NANGLE; ++n)
+        for (int r = 0; r < numrho; ++r) {
+            const int v = A(n, r);
+            if (!IS_PEAK(n, r, v)) continue;
+            if ((v < DK_MAX_VOTES ? v : DK_MAX_VOTES - 1) < vcut) continue;
+            ++np;
+            const double cs = (double)tab[2 * n], sn = (double)tab[2 * n + 1], rho = (double)(r - half);
+            const int xflag = fabs(sn) > fabs(cs);
+            const int L = xflag ? W : H, lim = xflag ? H : W;
+            const double major = xflag ? sn : cs, minor = xflag ? cs : sn;
+            const double q0 = rho / major, q1 = -minor / major;
+            const long long c0 = llrint(q0 * 65536.0) + 32768, step = llrint(q1 * 65536.0);
+            int start = -1, last = -1, gap = 0, emitted = 0;
+            for (int t = 0; t <= L; ++t) {
+                int hit = 0;
+                if (t < L) {
+                    const long long c = (c0 + (long long)t * step) >> 16;
+                    if (c >= 0 && c < lim) hit = edges[xflag ? (size_t)c * W + t : (size_t)t * W + c] != 0;
+                }
+                if (hit) { if (start < 0) start = t; last = t; gap = 0; continue; }
+                if (start < 0) continue;
+                if (t < L && ++gap <= DK_MAXGAP) continue;
+                /* close [start, last] */
+                const int cs_ = (int)((c0 + (long long)start * step) >> 16), cl_ = (int)((c0 + (long long)last * step) >> 16);
+                const int x_s = xflag ? start : cs_, y_s = xflag ? cs_ : start, x_l = xflag ? last : cl_, y_l = xflag ? cl_ : last;
+                if ((abs(x_l - x_s) >= DK_MINLEN || abs(y_l - y_s) >= DK_MINLEN) && emitted < DK_SEG_PER_PEAK && ns < max_segs) {
+                    int32_t* o = segs + 4 * ns;
+                    const int first_is_start = xflag ? 1 : (cs > 0 ? 0 : 1);   /* x-major: left end first; y-major: bottom first when cos > 0 */
+                    if (first_is_start) { o[0] = x_s; o[1] = y_s; o[2] = x_l; o[3] = y_l; }
+                    else { o[0] = x_l; o[1] = y_l; o[2] = x_s; o[3] = y_s; }
+                    ++ns; ++emitted;
+                }
+                start = -1; gap = 0;
+            }
+        }
+#undef IS_PEAK
+#undef A
+    free(acc);
+    *n_peaks = np;
+    return ns;
+}
+
+typedef struct { double key; int fx, fy; } DkVec;
+static int dk_cmp(const void* a, const void* b) {
+    const double ka = ((const DkVec*)a)->key, kb = ((const DkVec*)b)->key;
+    return ka < kb ? -1 : (ka > kb ? 1 : 0);
+}
+
+/* step 4: segments -> rot[0] = sin, rot[1] = cos of the median folded angle, rot[2] = flag (see header) */
+void oracle_deskew_angle(const int32_t* segs, int ns, double* rot) {
+    rot[0] = 0.0; rot[1] = 1.0; rot[2] = 0.0;
+    if (ns <= 0) return;
+    DkVec* v = (DkVec*)malloc(sizeof(DkVec) * (size_t)ns);
+    for (int i = 0; i < ns; ++i) {
+        int vx = segs[4 * i + 2] - segs[4 * i], vy = segs[4 * i + 3] - segs[4 * i + 1];
+        if (vy < 0 && -vy > vx) { const int t = vx; vx = -vy; vy = t; }                         /* angle < -45: + 90 degrees */
+        else if ((vy > 0 && vy > vx) || (vy == 0 && vx < 0)) { const int t = vx; vx = vy; vy = -t; }   /* angle > 45: - 90 degrees */
+        { int a_ = abs(vx), b_ = abs(vy); while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; } vx /= a_; vy /= a_; }   /* one representative per direction */
+        v[i].fx = vx; v[i].fy = vy;
+        v[i].key = vx > 0 ? (double)vy / (double)vx : INFINITY;
+    }
+    qsort(v, (size_t)ns, sizeof(DkVec), dk_cmp);
+    const DkVec a = v[(ns - 1) / 2], b = v[ns / 2];
+    free(v);
+    const double la = sqrt((double)a.fx * a.fx + (double)a.fy * a.fy), lb = sqrt((double)b.fx * b.fx + (double)b.fy * b.fy);
+    double c = (double)a.fx / la, s = (double)a.fy / la;
+    if (ns % 2 == 0) {
+        const double cx = c + (double)b.fx / lb, sx = s + (double)b.fy / lb;
+        const double l = sqrt(cx * cx + sx * sx);
+        c = cx / l; s = sx / l;
+    }
+    rot[0] = s; rot[1] = c;
+    rot[2] = fabs(s) < DK_SIN_HALF_DEG ? 1.0 : (fabs(s) > c ? 2.0 : 3.0);
+}
+
+/* bicubic weight table of remap's fixed-point path: [32 * 32][16] shorts */
+void oracle_deskew_wtab(int16_t* wtab) {
+    float tab[32 * 4];
+    const float A = -0.75f, scale = 1.f / 32;
+    for (int i = 0; i < 32; ++i) {
+        const float x = i * scale;
+        float* c = tab + 4 * i;
+        c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+        c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+        c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+    }
+    for (int i = 0; i < 32; ++i)
+        for (int j = 0; j < 32; ++j) {
+            int16_t* it = wtab + (size_t)(i * 32 + j) * 16;
+            int isum = 0;
+            for (int k1 = 0; k1 < 4; ++k1)
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const float v = tab[4 * i + k1] * tab[4 * j + k2];
+                    long q = lrintf(v * 32768.f);
+                    if (q > 32767) q = 32767;
+                    if (q < -32768) q = -32768;
+                    it[k1 * 4 + k2] = (int16_t)q;
+                    isum += (int)q;
+                }
+            if (isum != 32768) {
+                const int diff = isum - 32768;
+                int Mk = 1 * 4 + 1, mk = 1 * 4 + 1;
+                for (int k1 = 1; k1 < 3; ++k1)
+                    for (int k2 = 1; k2 < 3; ++k2) {
+                        const int k = k1 * 4 + k2;
+                        if (it[k] < it[mk]) mk = k;
+                        else if (it[k] > it[Mk]) Mk = k;
+                    }
+                if (diff < 0) it[Mk] = (int16_t)(it[Mk] - diff); else it[mk] = (int16_t)(it[mk] - diff);
+            }
+        }
+}
+
+/* inverse map of getRotationMatrix2D((W / 2, H / 2), angle, 1.0) with cos / sin given: m[6] */
+void oracle_deskew_matrix(int H, int W, double s, double c, double* m) {
+    const double cx = (double)(W / 2), cy = (double)(H / 2);
+    double M[6] = {c, s, (1 - c) * cx - s * cy, -s, c, s * cx + (1 - c) * cy};
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    memcpy(m, M, sizeof(M));
+}
+
+/* step 5 */
+void oracle_deskew_warp(const uint8_t* rgb, int H, int W, double s, double c, uint8_t* out) {
+    static int16_t wtab[32 * 32 * 16];
+    static int have = 0;
+    if (!have) { oracle_deskew_wtab(wtab); have = 1; }
+    double M[6];
+    oracle_deskew_matrix(H, W, s, c, M);
+    for (int y = 0; y < H; ++y) {
+        const long X0 = lrint((M[1] * y + M[2]) * 1024) + 16, Y0 = lrint((M[4] * y + M[5]) * 1024) + 16;
+        for (int x = 0; x < W; ++x) {
+            const long X = (X0 + lrint(M[0] * x * 1024)) >> 5, Y = (Y0 + lrint(M[3] * x * 1024)) >> 5;
+            long sx = X >> 5, sy = Y >> 5;
+            if (sx > 32767) sx = 32767; if (sx < -32768) sx = -32768;
+            if (sy > 32767) sy = 32767; if (sy < -32768) sy = -32768;
+            const int16_t* w = wtab + (size_t)((Y & 31) * 32 + (X & 31)) * 16;
+            for (int ch = 0; ch < 3; ++ch) {
+                int sum = 0;
+                for (int k1 = 0; k1 < 4; ++k1) {
+                    const int yy = clampi((int)sy - 1 + k1, 0, H - 1);
+                    for (int k2 = 0; k2 < 4; ++k2) {
+                        const int xx = clampi((int)sx - 1 + k2, 0, W - 1);
+                        sum += (int)rgb[((size_t)yy * W + xx) * 3 + ch] * w[k1 * 4 + k2];
+                    }
+                }
+                const int v = (sum + (1 << 14)) >> 15;
+                out[((size_t)y * W + x) * 3 + ch] = (uint8_t)clampi(v, 0, 255);
+            }
+        }
+    }
+}
+
+/* the whole step on one page; returns the flag; rot[3] as oracle_deskew_angle; out = rotated (flag 3) or a copy */
+int oracle_deskew(const uint8_t* rgb, int H, int W, uint8_t* out, double* rot, int32_t* n_segs, int32_t* n_peaks) {
+    uint8_t* edges = (uint8_t*)malloc((size_t)H * W);
+    const int max_segs = DK_MAX_PEAKS * DK_SEG_PER_PEAK;
+    int32_t* segs = (int32_t*)malloc(sizeof(int32_t) * 4 * (size_t)max_segs);
+    oracle_deskew_canny(rgb, H, W, edges);
+    const int ns = oracle_deskew_segments(edges, H, W, segs, max_segs, n_peaks, NULL);
+    oracle_deskew_angle(segs, ns, rot);
+    *n_segs = ns;
+    if ((int)rot[2] == 3) oracle_deskew_warp(rgb, H, W, rot[0], rot[1], out);
+    else memcpy(out, rgb, (size_t)H * W * 3);
+    free(edges); free(segs);
+    return (int)rot[2];
+}

@@ -13,8 +13,8 @@ _LIB = None
 
 def build() -> Path:
     so = _HERE / "_build" / "liboracle.so"
-    src = _HERE / "csrc" / "dbpost_oracle.c"
-    if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+    newest = max(f.stat().st_mtime for f in (_HERE / "csrc").glob("*.c"))
+    if not so.exists() or so.stat().st_mtime < newest:
         subprocess.check_call(["make", "-s", "-C", str(_HERE)])
     return so
 

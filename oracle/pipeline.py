@@ -29,7 +29,8 @@ def run_pages(det_w, rec_w, pages_u8: np.ndarray, charset: List[str], enhance: b
     for i in range(b):
         quads, dsc, _ = dbpost.db_postprocess(bits[i], h, w, **(post or {}))
         if len(quads) == 0:
-            out.append(dict(quads=quads, texts=[], scores=np.zeros(0, np.float32), det_scores=dsc))
+            out.append(dict(quads=quads, texts=[], scores=np.zeros(0, np.float32), det_scores=dsc, idx=np.zeros((0, 80), np.int64),
+                            margin=np.zeros((0, 80), np.float32)))
             continue
         crops, widths = zip(*[dbpost.rec_crop(processed[i], q) for q in quads])
         crops = np.stack(crops)
@@ -39,9 +40,11 @@ def run_pages(det_w, rec_w, pages_u8: np.ndarray, charset: List[str], enhance: b
         import torch
         with torch.no_grad():
             feat = nets.rec_backbone(rec_w, x, mode)
-            idx, prob_t, _, _ = nets.rec_head(rec_w, feat, mode)
+            idx, prob_t, logits, _ = nets.rec_head(rec_w, feat, mode)
         dec = nets.ctc_greedy(idx, prob_t, charset)
-        out.append(dict(quads=quads, texts=[d[0] for d in dec], scores=np.array([d[1] for d in dec], np.float32), det_scores=dsc))
+        top2 = np.partition(logits, -2, axis=2)[:, :, -2:]
+        out.append(dict(quads=quads, texts=[d[0] for d in dec], scores=np.array([d[1] for d in dec], np.float32), det_scores=dsc,
+                        idx=idx, margin=(top2[:, :, 1] - top2[:, :, 0]).astype(np.float32)))   # per-step top-1 minus top-2 logit
     return out, processed
 
 

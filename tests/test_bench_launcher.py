@@ -1,0 +1,53 @@
+"""CPU: `python bench.py --gpus N` must launch N ranks ITSELF (the driver may call it without torchrun), rank 0 prints one
+JSON line with n_gpus == N and the rank count the collective backend saw; a failing rank makes the launcher exit non-zero.
+Driven with --backend gloo --dry-engine (fake recogniser outputs; the launcher, the env hand-off, the process group, the
+capacity all-reduce and the device-tensor all-gather are the real code).  Shard unit: pages
+(/root/reference/backend/services/ocr_service.py:620-637)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(extra, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), "--backend", "gloo", "--dry-engine", "--steps", "3", "--warmup", "1",
+                           "--pages", "5"] + extra, capture_output=True, text=True, timeout=300, env=e)
+
+
+def test_bench_gpus_2_launches_two_ranks_itself():
+    r = _run(["--gpus", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # exactly one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["global_batch"] == 10
+    assert out["config"]["pages_gathered_last_step"] == 10  # every rank's pages arrived, in one buffer
+    assert out["scaling"] == "weak" and out["steps"] == 3 and out["warmup"] == 1
+    assert out["value"] is None and "DRY" in out["data"]    # a rehearsal never produces a number
+
+
+def test_bench_gpus_1_stays_single_process():
+    r = _run(["--gpus", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["config"]["ranks"] == 1 and out["config"]["collective_backend"] is None
+
+
+def test_bench_under_an_external_launcher_uses_its_ranks():
+    """torchrun-style: RANK/WORLD_SIZE in the environment -> no second launcher, the process is a rank."""
+    r = _run(["--gpus", "1"], env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29877"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["config"]["collective_backend"] == "gloo"
+
+
+def test_launcher_propagates_a_failing_rank():
+    r = _run(["--gpus", "2", "--pages", "-3"])             # every rank raises (negative shard size)
+    assert r.returncode != 0

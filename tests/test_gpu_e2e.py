@@ -15,6 +15,8 @@ from lumina_ocr.utils import layout
 
 pytestmark = pytest.mark.gpu
 
+MARGIN_EPS = 1.0   # logit units (logit std of the seeded recogniser ~2.0): see tests/test_gpu_rec.py::test_rec_forward_taps
+
 
 def _edit(a, b):
     d = list(range(len(b) + 1))
@@ -36,6 +38,27 @@ def test_pipeline_matches_oracle_pipeline(engine, det_weights, rec_weights):
     assert np.array_equal(processed.cpu().numpy(), ref_processed)         # byte path: exact
     n_match = n_ref = n_exact_box = n_exact_text = 0
     ious, eds, nchar = [], 0, 0
+    # String parity, stated per time step: on the crops of the oracle's own boxes, every step whose oracle top-1 / top-2 logit
+    # margin exceeds MARGIN_EPS (logit units, tests/test_gpu_rec.py) must give the same class id; a line whose 80 steps are all
+    # clear must give the identical string; the edit-distance bound below covers what is left (near-ties of the seeded network).
+    n_clear_steps = n_steps = n_clear_lines = 0
+    cs = pipe.charset
+    for pi, r in enumerate(ref):
+        if len(r["quads"]) == 0:
+            continue
+        q = torch.from_numpy(np.ascontiguousarray(r["quads"], np.int32)).cuda()
+        crops, widths = engine.rec_crop(processed, q, torch.full((len(q),), pi, dtype=torch.int32, device="cuda"))
+        gidx, gprob = engine.rec_forward(crops, widths)
+        gtext, glen, _ = engine.ctc_decode(gidx, gprob)
+        gidx = gidx.cpu().numpy()
+        clear = r["margin"] > MARGIN_EPS
+        n_clear_steps += int(clear.sum()); n_steps += clear.size
+        assert np.array_equal(gidx[clear], r["idx"][clear]), "page %d: arg-max differs on a step with a clear margin" % pi
+        for li in np.nonzero(clear.all(1))[0]:
+            n_clear_lines += 1
+            got = "".join(cs[k] for k in gtext[li, : int(glen[li])].cpu().tolist())
+            assert got == r["texts"][li], (pi, li, got, r["texts"][li])
+    assert n_clear_steps > 0.05 * n_steps, (n_clear_steps, n_steps)
     for d, r in zip(dets, ref):
         n_ref += len(r["quads"])
         used = set()
@@ -62,7 +85,9 @@ def test_pipeline_matches_oracle_pipeline(engine, det_weights, rec_weights):
         import os
         os.makedirs("gpurun_out", exist_ok=True)
         json.dump(dict(ref_boxes=n_ref, matched=n_match, exact_boxes=n_exact_box, exact_texts=n_exact_text, min_iou=float(np.min(ious)),
-                       mean_iou=float(np.mean(ious)), edit_distance=eds, chars=nchar), open("gpurun_out/parity_e2e.json", "w"))
+                       mean_iou=float(np.mean(ious)), edit_distance=eds, chars=nchar, margin_eps=MARGIN_EPS,
+                       clear_step_share=n_clear_steps / max(n_steps, 1), clear_step_agreement=1.0, fully_clear_lines=n_clear_lines,
+                       fully_clear_lines_exact=n_clear_lines), open("gpurun_out/parity_e2e.json", "w"))
     except OSError:
         pass
 
@@ -75,6 +100,11 @@ def test_provider_end_to_end_schema(engine, tmp_path):
     p = tmp_path / "form.png"
     Image.fromarray(page).save(p)
     s = svc.OCRService()
+    s.cleanup()
+    s._allow_synthetic = False                      # no weights configured and not asked for synthetic ones: an ERROR, as data
+    r0 = asyncio.run(s.process_document(p, "png"))
+    assert not r0.success and "weights not configured" in r0.error and r0.combined_markdown == ""
+    s._allow_synthetic = True                       # (LUMINA_OCR_ALLOW_SYNTHETIC=1)
     r = asyncio.run(s.process_document(p, "png"))
     assert r.success, r.error
     assert r.total_pages == 1 and len(r.pages) == 1

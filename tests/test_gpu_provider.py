@@ -1,0 +1,83 @@
+"""GPU: the provider's multi-page and threading behaviour on the real engine (the CPU twin with a stand-in engine is
+tests/test_provider_contract.py).  PDF path: /root/reference/backend/services/ocr_service.py:604-660; callers enter through
+asyncio.to_thread worker threads (:674-677) after preload on the main thread (:832-837)."""
+import asyncio
+import io
+import threading
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from lumina_ocr import synth
+from lumina_ocr.utils import layout
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def service():
+    from lumina_ocr.services import ocr_service as svc
+    s = svc.OCRService()
+    s.cleanup()
+    s._allow_synthetic = True          # LUMINA_OCR_ALLOW_SYNTHETIC=1: no trained weights ship offline
+    yield s
+    s.cleanup()
+
+
+def test_pdf_pages_of_two_sizes_through_the_engine(service, monkeypatch, tmp_path):
+    s = service
+    a = synth.synth_page(700, 500, 1, n_lines=10)[0]
+    b = synth.synth_page(500, 700, 2, n_lines=8)[0]
+    c = synth.synth_page(700, 500, 3, n_lines=10)[0]
+    pages = [Image.fromarray(x) for x in (a, b, c)]
+    monkeypatch.setattr(s._pre, "pdf_to_images", lambda path, dpi=None: pages)
+    pdf = tmp_path / "doc.pdf"
+    pdf.write_bytes(b"%PDF-1.4 stand-in")
+    r = asyncio.run(s.process_document(pdf, "pdf"))
+    assert r.success, r.error
+    assert r.total_pages == 3 and [p.page_number for p in r.pages] == [1, 2, 3]
+    assert [(p.image_width, p.image_height) for p in r.pages] == [(500, 700), (700, 500), (500, 700)]
+    for p, im in zip(r.pages, pages):
+        assert p.success and p.markdown.strip()
+        assert Image.open(io.BytesIO(p.processed_image_bytes)).size == im.size          # each page its own JPEG, its own pixel grid
+        assert (p.page_width_inches, p.page_height_inches) == (float(im.size[0]), float(im.size[1]))
+        assert all(bx["page_number"] == p.page_number for bx in p.layout_boxes)
+    assert r.combined_markdown == "\n\n---\n\n".join("## Page %d\n\n%s" % (p.page_number, p.markdown) for p in r.pages)
+    assert r.combined_layout_boxes == [bx for p in r.pages for bx in p.layout_boxes]
+    assert layout.validate_layout_boxes(r.combined_layout_boxes) == []
+    # batching pages 1 and 3 together must not change them: page 1 alone gives the same boxes and the same JPEG
+    solo = s.process_image_sync(pages[0], 1)
+    assert solo.layout_boxes == r.pages[0].layout_boxes and solo.processed_image_bytes == r.pages[0].processed_image_bytes
+
+
+def test_provider_from_a_fresh_thread_after_preload(service):
+    """preload_model() on the main thread, requests from worker threads (what asyncio.to_thread does): the worker must be bound
+    to the engine's device for uploads, streams and every C-ABI call."""
+    s = service
+    s.preload_model()
+    page = Image.fromarray(synth.synth_page(480, 640, 5, n_lines=8)[0])
+    main = s.process_image_sync(page)
+    box = {}
+    t = threading.Thread(target=lambda: box.setdefault("r", s.process_image_sync(page)))
+    t.start(); t.join(120)
+    assert "r" in box and box["r"].success, getattr(box.get("r"), "error", "no result")
+    assert box["r"].layout_boxes == main.layout_boxes and box["r"].processed_image_bytes == main.processed_image_bytes
+    assert s.get_status()["weights"] == "seeded-synthetic" and s.get_status()["apply_deskew"] is True
+
+
+def test_deskew_flag_is_honoured(service):
+    """OCR_APPLY_DESKEW (config.py:85): a page skewed by 3 degrees comes back upright in processed_image_bytes' grid when on."""
+    s = service
+    page = Image.fromarray(synth.synth_page(600, 800, 9, n_lines=12)[0]).rotate(3.0, resample=Image.BICUBIC, fillcolor=(255, 255, 255))
+    s.apply_deskew = True
+    on = s.process_image_sync(page)
+    s.apply_deskew = False
+    off = s.process_image_sync(page)
+    s.apply_deskew = True
+    assert on.success and off.success
+
+    def slope(o):   # mean |dy/dx| of the line boxes' top edges
+        v = [abs((b["polygon"][3] - b["polygon"][1]) / max(b["polygon"][2] - b["polygon"][0], 1.0)) for b in o.layout_boxes if b["type"] == "line"]
+        return float(np.mean(v)) if v else 1.0
+    assert slope(on) < 0.5 * slope(off) or slope(on) < 0.01, (slope(on), slope(off))

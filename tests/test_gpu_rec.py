@@ -8,6 +8,8 @@ from lumina_ocr import arch, synth
 
 pytestmark = pytest.mark.gpu
 
+MARGIN_EPS = 1.0   # logit units; see test_rec_forward_taps
+
 
 def _crops(n, seed):
     rng = np.random.default_rng(seed)
@@ -44,13 +46,22 @@ def test_rec_forward_taps(engine, rec_weights):
     engine.set_option("keep_taps", 0)
     agree = float((idx.cpu().numpy() == ridx).mean())
     assert agree > 0.8, agree
+    # The string-parity statement (north_star: "exact or within stated edit-distance"): the seeded network's logits (std ~2.0)
+    # have near-ties at most steps, and bf16 drift through 2 x 80 recurrent steps moves a logit by <= ~0.9 (p99; measured with
+    # tools/margin_probe.py: largest margin of a flipped arg-max 0.52).  EVERY time step whose oracle top-1 / top-2 logit margin
+    # exceeds MARGIN_EPS must carry the same class id; the looser agreement bound above only covers the near-ties.
+    top2 = np.partition(logits, -2, axis=2)[:, :, -2:]
+    clear = (top2[:, :, 1] - top2[:, :, 0]) > MARGIN_EPS
+    assert clear.mean() > 0.05, float(clear.mean())
+    assert np.array_equal(idx.cpu().numpy()[clear], ridx[clear]), "arg-max differs on a step with a clear margin"
     same = idx.cpu().numpy() == ridx
     gp, rp = prob.cpu().numpy()[same], rprob[same]
     rel = float(np.abs(gp - rp).mean() / max(rp.mean(), 1e-9))
     try:
         import json, os
         os.makedirs("gpurun_out", exist_ok=True)
-        json.dump(dict(argmax_agreement=agree, prob_mean_rel_err=rel), open("gpurun_out/parity_rec.json", "w"))
+        json.dump(dict(argmax_agreement=agree, prob_mean_rel_err=rel, margin_eps=MARGIN_EPS, clear_step_share=float(clear.mean()),
+                       clear_step_agreement=1.0), open("gpurun_out/parity_rec.json", "w"))
     except OSError:
         pass
     assert rel < 0.1, rel
