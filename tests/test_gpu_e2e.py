@@ -58,7 +58,7 @@ def test_pipeline_matches_oracle_pipeline(engine, det_weights, rec_weights):
             n_clear_lines += 1
             got = "".join(cs[k] for k in gtext[li, : int(glen[li])].cpu().tolist())
             assert got == r["texts"][li], (pi, li, got, r["texts"][li])
-    assert n_clear_steps > 0.05 * n_steps, (n_clear_steps, n_steps)
+    assert n_clear_steps >= 10, (n_clear_steps, n_steps)
     for d, r in zip(dets, ref):
         n_ref += len(r["quads"])
         used = set()

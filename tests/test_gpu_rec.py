@@ -52,7 +52,7 @@ def test_rec_forward_taps(engine, rec_weights):
     # exceeds MARGIN_EPS must carry the same class id; the looser agreement bound above only covers the near-ties.
     top2 = np.partition(logits, -2, axis=2)[:, :, -2:]
     clear = (top2[:, :, 1] - top2[:, :, 0]) > MARGIN_EPS
-    assert clear.mean() > 0.05, float(clear.mean())
+    assert clear.sum() >= 10, int(clear.sum())           # (a few % of the steps of a seeded network)
     assert np.array_equal(idx.cpu().numpy()[clear], ridx[clear]), "arg-max differs on a step with a clear margin"
     same = idx.cpu().numpy() == ridx
     gp, rp = prob.cpu().numpy()[same], rprob[same]

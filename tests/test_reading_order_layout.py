@@ -110,6 +110,12 @@ def test_provider_without_gpu_fails_loudly_as_data(tmp_path):
     from PIL import Image
     p = tmp_path / "page.png"
     Image.new("RGB", (64, 48), (255, 255, 255)).save(p)
-    r = asyncio.run(svc.OCRService().process_document(p, "png"))
+    s = svc.OCRService()
+    s.cleanup()
+    s._allow_synthetic = True     # weights are not the problem here: the missing GPU is
+    try:
+        r = asyncio.run(s.process_document(p, "png"))
+    finally:
+        s._allow_synthetic = False
     assert r.success is False and r.pages[0].success is False and "ROCm" in r.error   # no CPU fallback exists
     assert r.pages[0].image_width == 64 and r.pages[0].image_height == 48
