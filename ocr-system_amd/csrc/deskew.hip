@@ -119,31 +119,42 @@ __global__ __launch_bounds__(256) void cc_mark_kernel(const uint8_t* map, const 
     const size_t pg = i / per_page;
     mark[pg * per_page + uf_find(label + pg * per_page, (int)(i - pg * per_page))] = 1;   // every writer stores the same value
 }
-// edges + compacted list of edge pixels per page (order irrelevant: votes are integer sums)
+// edges + compacted list of edge pixels per page (order irrelevant: votes are integer sums).  One work-group = 2048 consecutive
+// pixels of ONE page (8 per thread), one atomic per work-group: a counter per page takes ~1.4 k adds instead of one per wave.
+constexpr int CE_PX = 8, CE_BLOCK = 256 * CE_PX;
 __global__ __launch_bounds__(256) void cc_edges_kernel(const uint8_t* map, const int* label, const int* mark, uint8_t* edges, int* list, int* count,
-                                                        int W, size_t total, size_t per_page) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = i < total;
-    const size_t pg = valid ? i / per_page : 0;
-    bool e = false;
-    int li = 0;
-    if (valid && map[i] != 1) {
-        li = (int)(i - pg * per_page);
-        e = mark[pg * per_page + uf_find(label + pg * per_page, li)] != 0;
+                                                        int W, int blocks_per_page, size_t per_page) {
+    __shared__ int s_wave[4], s_base;
+    const int pg = blockIdx.x / blocks_per_page, blk = blockIdx.x - pg * blocks_per_page;
+    const size_t pbase = (size_t)pg * per_page;
+    const int li0 = blk * CE_BLOCK + threadIdx.x * CE_PX;
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < CE_PX; ++k) {
+        const int li = li0 + k;
+        if ((size_t)li >= per_page) break;
+        bool e = false;
+        if (map[pbase + li] != 1) e = mark[pbase + uf_find(label + pbase, li)] != 0;
+        edges[pbase + li] = e ? 255 : 0;
+        bits |= (unsigned)e << k;
     }
-    if (valid) edges[i] = e ? 255 : 0;
-    // a wave may straddle two pages only at a page boundary: append per lane's page with one atomic per (wave, page)
-    const size_t pg0 = (size_t)__shfl((int)pg, 0);
-    for (int k = 0; k < 2; ++k) {
-        const size_t pk = pg0 + k;
-        const unsigned long long mask = __ballot(e && pg == pk);
-        if (!mask) continue;
-        const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&count[pk], __popcll(mask));
-        base = __shfl(base, leader);
-        if (e && pg == pk) list[pk * per_page + base + __popcll(mask & ((1ull << lane) - 1ull))] = ((li / W) << 16) | (li % W);
+    const int mine = __popc(bits), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = mine;                                     // inclusive prefix over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = tot ? atomicAdd(&count[pg], tot) : 0;
     }
+    __syncthreads();
+    int pos = s_base + incl - mine;
+    for (int w = 0; w < wave; ++w) pos += s_wave[w];
+    int* out = list + pbase;
+#pragma unroll
+    for (int k = 0; k < CE_PX; ++k)
+        if (bits & (1u << k)) { const int li = li0 + k; out[pos++] = ((li / W) << 16) | (li % W); }
 }
 
 // ---------------------------------------------------------------------------------------------- 3a: accumulator
@@ -374,15 +385,30 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* rgb, uint8_t* 
     sy = sy > 32767 ? 32767 : (sy < -32768 ? -32768 : sy);
     const short* w = wtab + (size_t)((Y & 31) * 32 + (X & 31)) * 16;
     int sum[3] = {0, 0, 0};
+    const int bx = (int)sx - 1, by = (int)sy - 1;
+    if (bx >= 0 && bx + 4 <= W && by >= 0 && by + 4 <= H && ((size_t)(pg + 1) * H * W * 3 - (((size_t)pg * H + by + 3) * W + bx) * 3) >= 16) {
+        // interior: the 4 pixels of a row are 12 contiguous bytes -> three (unaligned) dword loads instead of twelve byte loads
+        typedef uint32_t __attribute__((aligned(1))) u32u_t;
 #pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) {
-        const int yy = clampi((int)sy - 1 + k1, 0, H - 1);
+        for (int k1 = 0; k1 < 4; ++k1) {
+            const u32u_t* q = reinterpret_cast<const u32u_t*>(img + ((size_t)(by + k1) * W + bx) * 3);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+            const int w0 = w[k1 * 4], w1 = w[k1 * 4 + 1], w2 = w[k1 * 4 + 2], w3 = w[k1 * 4 + 3];
+            sum[0] += (int)(d0 & 255) * w0 + (int)(d0 >> 24) * w1 + (int)((d1 >> 16) & 255) * w2 + (int)((d2 >> 8) & 255) * w3;
+            sum[1] += (int)((d0 >> 8) & 255) * w0 + (int)(d1 & 255) * w1 + (int)(d1 >> 24) * w2 + (int)((d2 >> 16) & 255) * w3;
+            sum[2] += (int)((d0 >> 16) & 255) * w0 + (int)((d1 >> 8) & 255) * w1 + (int)(d2 & 255) * w2 + (int)(d2 >> 24) * w3;
+        }
+    } else {
 #pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) {
-            const int xx = clampi((int)sx - 1 + k2, 0, W - 1);
-            const uint8_t* p = img + ((size_t)yy * W + xx) * 3;
-            const int wv = w[k1 * 4 + k2];
-            sum[0] += p[0] * wv; sum[1] += p[1] * wv; sum[2] += p[2] * wv;
+        for (int k1 = 0; k1 < 4; ++k1) {
+            const int yy = clampi(by + k1, 0, H - 1);
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                const int xx = clampi(bx + k2, 0, W - 1);
+                const uint8_t* p = img + ((size_t)yy * W + xx) * 3;
+                const int wv = w[k1 * 4 + k2];
+                sum[0] += p[0] * wv; sum[1] += p[1] * wv; sum[2] += p[2] * wv;
+            }
         }
     }
 #pragma unroll
@@ -477,7 +503,8 @@ hipError_t deskew_launch(const DeskewParams& p, void* workspace, hipStream_t st)
     hipLaunchKernelGGL(cc_init_kernel, dim3(nb), dim3(256), 0, st, map, label, mark, px, per);
     hipLaunchKernelGGL(cc_merge_kernel, dim3(nb), dim3(256), 0, st, map, label, H, W, px);
     hipLaunchKernelGGL(cc_mark_kernel, dim3(nb), dim3(256), 0, st, map, label, mark, px, per);
-    hipLaunchKernelGGL(cc_edges_kernel, dim3(nb), dim3(256), 0, st, map, label, mark, edges, list, count, W, px, per);
+    const int bpp = (int)((per + CE_BLOCK - 1) / CE_BLOCK);
+    hipLaunchKernelGGL(cc_edges_kernel, dim3((unsigned)(B * bpp)), dim3(256), 0, st, map, label, mark, edges, list, count, W, bpp, per);
     { hipError_t e2 = locr_dyn_lds(reinterpret_cast<const void*>(hough_kernel), 150 * 1024); if (e2 != hipSuccess) return e2; }
     hipLaunchKernelGGL(hough_kernel, dim3(DK_NANGLE / 2, B), dim3(256), (size_t)2 * numrho * 4, st, list, count, p.trig, accum, numrho, per);
     hipLaunchKernelGGL(peak_hist_kernel, dim3(DK_NANGLE, B), dim3(256), 0, st, accum, hist, numrho);
