@@ -41,7 +41,8 @@ const char* lumina_ocr_last_error(const lumina_ocr_t* h);
 const char* lumina_ocr_version(void);
 /* options: "det_sub_batch", "rec_sub_batch", "post_group", "keep_taps", "time_convs"; developer A/B switches (results are
  * bit-identical either way): "fuse_head", "fuse_pool", "fuse_stem", "fuse_mb", "conv_ring", "ring_orient", "conv_big_min",
- * "blocked_layout" (experiment: fails loudly when a blocked tensor would reach a kernel other than the ring kernel) */
+ * "blocked_layout" (experiment: fails loudly when a blocked tensor would reach a kernel other than the ring kernel);
+ * "svtr_f16" (storage type of the next SVTR load), "conv2d_variant" (kernel choice of lumina_ocr_conv2d, parity tests) */
 int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value);
 
 /* weights: "LOCW" container (ocr-system_amd/lumina_ocr/arch.py write_blob), host memory.
@@ -108,14 +109,18 @@ int lumina_ocr_deskew(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int heig
 int lumina_ocr_deskew_warp(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, const double* rot_dev, uint8_t* out_dev,
                            void* stream);
 
-/* Second recogniser family (BASELINE configs[4]: SVTR): same slot and the same outputs as lumina_ocr_load_rec_weights /
- * lumina_ocr_rec_forward (the `rec` model of the engine call, ocr_service_paddleocr_backup.py:232-238, :285), with an SVTR-Tiny
- * backbone (patch embedding, local / global mixing blocks, CTC head) instead of CRNN.  Blob: LOCW with the `svtr.*` tensors of
- * lumina_ocr/arch.py make_svtr_weights. */
+/* Second recogniser family (BASELINE configs[4]: "SVTR-base multilingual (Hindi dict), fp16 MFMA"): same slot and the same outputs as
+ * lumina_ocr_load_rec_weights / lumina_ocr_rec_forward (the `rec` model of the engine call, ocr_service_paddleocr_backup.py:232-238,
+ * :285), with an SVTR backbone (patch embedding, local / global mixing blocks, CTC head) instead of CRNN.  Blob: LOCW with the
+ * `svtr.*` tensors of lumina_ocr/arch.py make_svtr_weights; the optional f32 tensor `svtr.config` = [dim0, dim1, dim2, depth0,
+ * depth1, depth2, heads0, heads1, heads2, local_blocks, out_channels, dtype] selects the variant (absent: SVTR-Tiny, bf16;
+ * Base = 128/256/384, 3/6/9, 4/8/12, 8 local blocks) and the storage / MFMA type (0 bf16, 1 fp16: v_mfma_f32_32x32x16_f16,
+ * activations and weights stored as IEEE half); option "svtr_f16" (0 / 1, -1 = as the blob says) overrides the type at load time. */
 int lumina_ocr_load_svtr_weights(lumina_ocr_t* h, const void* blob, size_t nbytes);
 int lumina_ocr_svtr_forward(lumina_ocr_t* h, const uint8_t* crops_dev, const int32_t* widths_dev, int n_crops, int32_t* idx_dev, float* prob_dev,
                             void* stream);
 int lumina_ocr_svtr_num_classes(const lumina_ocr_t* h);   /* class count of the loaded SVTR head (lumina_ocr_num_classes: the CRNN's) */
+int lumina_ocr_svtr_dtype(const lumina_ocr_t* h);         /* storage / MFMA type of the loaded SVTR model: 0 bf16, 1 fp16 */
 
 /* JPEG hand-off of the processed page: replaces image.save(buffer, format='JPEG', quality=q, optimize=True) inside
  * ImagePreprocessor.compress_for_azure (backend/utils/image_preprocessing.py:526-538; the bytes become OCROutput.processed_image_bytes,

@@ -78,6 +78,7 @@ int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value) {
     else if (!strcmp(key, "conv_big_min")) h->conv_big_min = value >= 0 ? value : 1024;
     else if (!strcmp(key, "ring_orient")) h->ring_orient = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "post_group")) h->post_group = value > 0 ? value : 1;
+    else if (!strcmp(key, "svtr_f16")) h->svtr_f16 = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "conv2d_variant")) h->conv2d_variant = value < 0 || value > 2 ? 0 : value;
     else return locr_fail(h, "set_option: unknown key", key);
     return 0;
@@ -407,6 +408,7 @@ int lumina_ocr_deskew_warp(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int
 }
 
 int lumina_ocr_svtr_num_classes(const lumina_ocr_t* h) { return h ? h->svtr.num_classes : 0; }
+int lumina_ocr_svtr_dtype(const lumina_ocr_t* h) { return h ? h->svtr.dtype : 0; }
 
 int lumina_ocr_conv_timing_detail(lumina_ocr_t* h, char* buf, size_t cap) {
     if (!h || !buf || cap == 0) return 1;

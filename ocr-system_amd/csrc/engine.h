@@ -46,15 +46,22 @@ struct RecBlock {
     SeLayer sel;
 };
 
-// SVTR-Tiny recogniser (arch.svtr_block_table): every linear layer is a 1x1 ConvLayer run in flat-GEMM mode
-struct SvtrBlock { int dim = 0, heads = 0, gh = 0, gw = 0; bool local = false; ConvLayer qkv, proj, fc1, fc2; float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr; };
+// SVTR recogniser (arch.svtr_block_table; Tiny or Base: the dimensions travel in the blob's svtr.config tensor).  Every linear layer
+// and every convolution is one svtr_gemm launch (svtr.h); proj / fc2 / the merging convs carry the LayerNorm that follows them.
+struct SvtrLinear {
+    int K = 0, N = 0, taps = 1, cin = 0, act = ACT_NONE;
+    uint16_t* w = nullptr;   // device, [N][K] in the model's storage type
+    float* bias = nullptr;
+    float *gamma = nullptr, *beta = nullptr;   // LayerNorm fused into the epilogue (or null)
+};
+struct SvtrBlock { int dim = 0, heads = 0, gh = 0, gw = 0; bool local = false; SvtrLinear qkv, proj, fc1, fc2; };
 struct SvtrModel {
     bool loaded = false;
+    int dtype = 0;            // storage / MFMA type: 0 bf16, 1 fp16
+    int dims[3] = {64, 128, 256}, depths[3] = {3, 6, 3}, heads[3] = {2, 4, 8}, local_blocks = 6, out_ch = 192;
     int num_classes = 0, ctc_ntiles = 0;
-    bf16_t* pe1_wpk = nullptr; float* pe1_bias = nullptr;   // patch embedding conv 1 (3 -> 32, stride 2): stem kernel
-    ConvLayer pe2, sub[2], last;
-    float *sub_g[2] = {nullptr, nullptr}, *sub_b[2] = {nullptr, nullptr};
-    bf16_t* pos = nullptr;
+    SvtrLinear pe1, pe2, sub[2], last;
+    uint16_t* pos = nullptr;  // [640][dims[0]]
     std::vector<SvtrBlock> blocks;
     bf16_t* ctc_wpk = nullptr; float* ctc_bias = nullptr;
 };
@@ -89,6 +96,7 @@ struct lumina_ocr {
     int conv_big_min = 1024;  // 16x32-tile kernels once a full sub-batch gives at least this many work-groups
     bool blocked_layout = false;  // stage-0 activations in channel-blocked layout (experiment)
     bool conv_ring = true;  // persistent ring kernel for the 3x3 / stride-1 layers (conv_ring.hip)
+    int svtr_f16 = -1;      // storage type of the next SVTR load: -1 = what the blob's svtr.config says, 0 bf16, 1 fp16
     int conv2d_variant = 0; // lumina_ocr_conv2d: 0 = the layer's default kernel, 1 = LDS-DMA 16x32 tile, 2 = ring kernel (tests)
     int ring_orient = -1;   // its tile orientation: -1 auto, 0 / 1 forced (tests)
     bool fuse_stem = true;  // stem.conv1 + stem.conv2 in one kernel (the first 32-channel tensor stays in LDS)

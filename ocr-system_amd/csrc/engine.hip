@@ -640,11 +640,49 @@ int eng_rec_forward(lumina_ocr* eng, const uint8_t* crops, const int* widths, in
     return 0;
 }
 
-// ------------------------------------------------------------------------------ SVTR-Tiny recogniser
+// ------------------------------------------------------------------------------ SVTR recogniser (Tiny / Base, bf16 / fp16)
 static float* upload_f32(lumina_ocr* eng, const std::map<std::string, HostBlobTensor>& m, const std::string& name, int n) {
     auto it = m.find(name);
     if (it == m.end() || it->second.dtype != 0 || (int)it->second.dims[0] != n) { locr_fail(eng, "missing/ill-shaped f32 tensor", name.c_str()); return nullptr; }
     return static_cast<float*>(dev_upload(eng, it->second.data, sizeof(float) * n));
+}
+
+static inline uint16_t bf16_bits_to(uint16_t b, int dtype) {   // bf16 bits -> the model's storage type (fp16: exact for |w| >= 2^-14)
+    if (!dtype) return b;
+    uint32_t u = (uint32_t)b << 16;
+    float f; memcpy(&f, &u, 4);
+    const _Float16 hv = (_Float16)f;
+    uint16_t o; memcpy(&o, &hv, 2);
+    return o;
+}
+
+// name.w [N][ks][ks][cin] bf16 (+ name.b) -> SvtrLinear with w [N][taps * cin_pad] in the storage type; ln != "" fuses that LayerNorm
+static bool make_linear(lumina_ocr* eng, const std::map<std::string, HostBlobTensor>& m, const std::string& name, int ks, int cin, int cin_pad, int N, int act,
+                        const std::string& ln, int dtype, bool flat_k, SvtrLinear* L) {
+    const HostBlobTensor *w, *b;
+    if (!get_wb(eng, m, name, &w, &b)) return false;
+    if (w->dims.size() != 4 || w->dims[0] != N || w->dims[1] != ks || w->dims[2] != ks || w->dims[3] != cin || (int)b->dims[0] != N) {
+        locr_fail(eng, "unexpected tensor shape", name.c_str());
+        return false;
+    }
+    const int taps = ks * ks;
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(w->data);
+    // flat_k: the taps * cin real values of a row are packed densely and the ROW is padded to cin_pad (patch embedding 1: 27 -> 32)
+    const int K = flat_k ? cin_pad : taps * cin_pad;
+    std::vector<uint16_t> packed((size_t)N * K, 0);
+    for (int n = 0; n < N; ++n)
+        for (int t = 0; t < taps; ++t)
+            for (int c = 0; c < cin; ++c)
+                packed[(size_t)n * K + (flat_k ? t * cin + c : t * cin_pad + c)] = bf16_bits_to(src[((size_t)n * taps + t) * cin + c], dtype);
+    L->K = K; L->N = N; L->taps = flat_k ? 1 : taps; L->cin = flat_k ? cin_pad : cin_pad; L->act = act;
+    L->w = static_cast<uint16_t*>(dev_upload(eng, packed.data(), packed.size() * 2));
+    L->bias = static_cast<float*>(dev_upload(eng, b->data, sizeof(float) * N));
+    if (!ln.empty()) {
+        L->gamma = upload_f32(eng, m, ln + ".g", N); L->beta = upload_f32(eng, m, ln + ".b", N);
+        if (!L->gamma || !L->beta) return false;
+    }
+    if (!L->w || !L->bias) { locr_fail(eng, "device upload failed", name.c_str()); return false; }
+    return true;
 }
 
 int eng_load_svtr(lumina_ocr* eng, const void* blob, size_t n) {
@@ -653,56 +691,66 @@ int eng_load_svtr(lumina_ocr* eng, const void* blob, size_t n) {
     HIPCHK(hipSetDevice(eng->device));
     SvtrModel& M = eng->svtr;
     M = SvtrModel();
-    const int dims[3] = {64, 128, 256}, depths[3] = {3, 6, 3}, heads[3] = {2, 4, 8};
-    {
-        const HostBlobTensor *w, *b;
-        if (!get_wb(eng, m, "svtr.pe1", &w, &b)) return 1;
-        if (w->dims.size() != 4 || w->dims[0] != 32 || w->dims[1] != 3 || w->dims[3] != 3) return locr_fail(eng, "svtr.pe1", "shape");
-        bf16_t packed[2 * 2 * 32 * 8];
-        pack_stem_weights(reinterpret_cast<const bf16_t*>(w->data), 32, packed);
-        M.pe1_wpk = static_cast<bf16_t*>(dev_upload(eng, packed, sizeof(packed)));
-        M.pe1_bias = static_cast<float*>(dev_upload(eng, b->data, 32 * sizeof(float)));
+    {   // variant + storage type
+        auto it = m.find("svtr.config");
+        if (it != m.end()) {
+            if (it->second.dtype != 0 || it->second.dims.size() != 1 || it->second.dims[0] != 12) return locr_fail(eng, "svtr.config", "expected 12 f32 values");
+            const float* c = reinterpret_cast<const float*>(it->second.data);
+            for (int i = 0; i < 3; ++i) { M.dims[i] = (int)c[i]; M.depths[i] = (int)c[3 + i]; M.heads[i] = (int)c[6 + i]; }
+            M.local_blocks = (int)c[9]; M.out_ch = (int)c[10]; M.dtype = (int)c[11] != 0;
+        }
+        if (eng->svtr_f16 >= 0) M.dtype = eng->svtr_f16;
+        for (int i = 0; i < 3; ++i) {
+            const int d = M.dims[i];
+            if (!(d == 64 || d == 128 || d == 256 || d == 384) || M.heads[i] * 32 != d || M.depths[i] < 1 || M.depths[i] > 32)
+                return locr_fail(eng, "svtr.config", "dims must be 64 / 128 / 256 / 384 with 32-wide heads");
+        }
+        if (M.out_ch != 192 || M.dims[0] > 128) return locr_fail(eng, "svtr.config", "out_channels must be 192 (CTC head K), dims[0] <= 128");
     }
-    if (!make_conv(eng, m, "svtr.pe2", 3, 2, 32, 64, 32, 64, ACT_GELU, &M.pe2)) return 1;
+    const int dt = M.dtype, d0 = M.dims[0];
+    if (!make_linear(eng, m, "svtr.pe1", 3, 3, 32, d0 / 2, ACT_GELU, "", dt, true, &M.pe1)) return 1;
+    if (!make_linear(eng, m, "svtr.pe2", 3, d0 / 2, d0 / 2, d0, ACT_GELU, "", dt, false, &M.pe2)) return 1;
     {
         auto it = m.find("svtr.pos.w");
-        if (it == m.end() || it->second.dtype != 1 || it->second.dims.size() != 2 || it->second.dims[0] != 640 || it->second.dims[1] != 64)
+        if (it == m.end() || it->second.dtype != 1 || it->second.dims.size() != 2 || it->second.dims[0] != 640 || it->second.dims[1] != d0)
             return locr_fail(eng, "svtr.pos", "missing/shape");
-        M.pos = static_cast<bf16_t*>(dev_upload(eng, it->second.data, it->second.nbytes));
+        const bf16_t* src = reinterpret_cast<const bf16_t*>(it->second.data);
+        std::vector<uint16_t> pos((size_t)640 * d0);
+        for (size_t i = 0; i < pos.size(); ++i) pos[i] = bf16_bits_to(src[i], dt);
+        M.pos = static_cast<uint16_t*>(dev_upload(eng, pos.data(), pos.size() * 2));
+        if (!M.pos) return locr_fail(eng, "upload", "svtr.pos");
     }
     int idx = 0, gh = 8;
     for (int s = 0; s < 3; ++s) {
-        const int c = dims[s];
-        for (int d = 0; d < depths[s]; ++d, ++idx) {
+        const int c = M.dims[s];
+        for (int d = 0; d < M.depths[s]; ++d, ++idx) {
             M.blocks.emplace_back();
             SvtrBlock& B = M.blocks.back();
-            B.dim = c; B.heads = heads[s]; B.gh = gh; B.gw = 80; B.local = idx < 6;
+            B.dim = c; B.heads = M.heads[s]; B.gh = gh; B.gw = 80; B.local = idx < M.local_blocks;
+            if (B.local && gh % 4 != 0) return locr_fail(eng, "svtr.config", "local mixing blocks need a token grid of at least 4 rows");
             const std::string p = "svtr.b" + std::to_string(idx);
-            if (!make_conv(eng, m, p + ".qkv", 1, 1, c, 3 * c, c, 3 * c, ACT_NONE, &B.qkv)) return 1;
-            if (!make_conv(eng, m, p + ".proj", 1, 1, c, c, c, c, ACT_NONE, &B.proj)) return 1;
-            if (!make_conv(eng, m, p + ".fc1", 1, 1, c, 4 * c, c, 4 * c, ACT_GELU, &B.fc1)) return 1;
-            if (!make_conv(eng, m, p + ".fc2", 1, 1, 4 * c, c, 4 * c, c, ACT_NONE, &B.fc2)) return 1;
-            B.ln1g = upload_f32(eng, m, p + ".ln1.g", c); B.ln1b = upload_f32(eng, m, p + ".ln1.b", c);
-            B.ln2g = upload_f32(eng, m, p + ".ln2.g", c); B.ln2b = upload_f32(eng, m, p + ".ln2.b", c);
-            if (!B.ln1g || !B.ln1b || !B.ln2g || !B.ln2b) return 1;
+            if (!make_linear(eng, m, p + ".qkv", 1, c, c, 3 * c, ACT_NONE, "", dt, false, &B.qkv)) return 1;
+            if (!make_linear(eng, m, p + ".proj", 1, c, c, c, ACT_NONE, p + ".ln1", dt, false, &B.proj)) return 1;
+            if (!make_linear(eng, m, p + ".fc1", 1, c, c, 4 * c, ACT_GELU, "", dt, false, &B.fc1)) return 1;
+            if (!make_linear(eng, m, p + ".fc2", 1, 4 * c, 4 * c, c, ACT_NONE, p + ".ln2", dt, false, &B.fc2)) return 1;
         }
         if (s < 2) {
             const std::string p = "svtr.sub" + std::to_string(s);
-            if (!make_conv(eng, m, p, 3, 1, c, dims[s + 1], c, dims[s + 1], ACT_NONE, &M.sub[s])) return 1;  // run at stride 1, even rows kept
-            M.sub[s].small_only = true;
-            M.sub_g[s] = upload_f32(eng, m, p + ".ln.g", dims[s + 1]); M.sub_b[s] = upload_f32(eng, m, p + ".ln.b", dims[s + 1]);
-            if (!M.sub_g[s] || !M.sub_b[s]) return 1;
+            if (!make_linear(eng, m, p, 3, c, c, M.dims[s + 1], ACT_NONE, p + ".ln", dt, false, &M.sub[s])) return 1;
             gh /= 2;
         }
     }
-    if (!make_conv(eng, m, "svtr.last", 1, 1, 256, 192, 256, 192, ACT_HSWISH, &M.last)) return 1;
+    if (!make_linear(eng, m, "svtr.last", 1, M.dims[2], M.dims[2], M.out_ch, ACT_HSWISH, "", dt, false, &M.last)) return 1;
     {
         auto w = m.find("svtr.ctc.fc.w"), b = m.find("svtr.ctc.fc.b");
-        if (w == m.end() || b == m.end() || w->second.dims[1] != 192) return locr_fail(eng, "svtr.ctc.fc", "missing/shape");
+        if (w == m.end() || b == m.end() || w->second.dims.size() != 2 || w->second.dims[1] != M.out_ch) return locr_fail(eng, "svtr.ctc.fc", "missing/shape");
         const int C = w->second.dims[0];
         M.num_classes = C; M.ctc_ntiles = (C + 63) / 64;
-        std::vector<bf16_t> packed(ctc_packed_weight_elems(C, 192));
-        pack_ctc_weights(reinterpret_cast<const bf16_t*>(w->second.data), C, 192, packed.data());
+        std::vector<bf16_t> conv((size_t)C * M.out_ch);
+        const bf16_t* src = reinterpret_cast<const bf16_t*>(w->second.data);
+        for (size_t i = 0; i < conv.size(); ++i) conv[i] = bf16_bits_to(src[i], dt);
+        std::vector<bf16_t> packed(ctc_packed_weight_elems(C, M.out_ch));
+        pack_ctc_weights(conv.data(), C, M.out_ch, packed.data());
         std::vector<float> bias((size_t)M.ctc_ntiles * 64, -1.0e30f);
         memcpy(bias.data(), b->second.data, sizeof(float) * C);
         M.ctc_wpk = static_cast<bf16_t*>(dev_upload(eng, packed.data(), packed.size() * sizeof(bf16_t)));
@@ -713,65 +761,70 @@ int eng_load_svtr(lumina_ocr* eng, const void* blob, size_t n) {
     return 0;
 }
 
+// one svtr_gemm launch: y = epi(gather(x) w^T + b)
+static int run_linear(lumina_ocr* eng, const SvtrLinear& L, const Tensor4& x, Tensor4* y, const bf16_t* res, int res_mod, int res_post, int hin, int win,
+                      int hout, int wout, int sh, int sw, bool dry, hipStream_t st) {
+    if (dry) return 0;
+    if (eng->zero_block == nullptr) {
+        const uint32_t z[64] = {0};
+        eng->zero_block = static_cast<bf16_t*>(dev_upload(eng, z, sizeof(z)));
+        if (!eng->zero_block) return locr_fail(eng, "svtr", "zero block upload failed");
+    }
+    SvtrGemmParams p{};
+    p.x = x.p; p.w = L.w; p.bias = L.bias; p.res = res; p.res_mod = res_mod; p.res_post = res_post; p.gamma = L.gamma; p.beta = L.beta; p.y = y->p;
+    p.zeros = eng->zero_block; p.M = (int)(y->elems() / L.N); p.K = L.K; p.N = L.N; p.act = L.act; p.eps = 1e-6f;
+    p.taps = L.taps; p.Cin = L.cin; p.Hin = hin; p.Win = win; p.Tout = hout * wout; p.Wout = wout; p.sh = sh; p.sw = sw;
+    if (x.c != L.cin || y->c != L.N) return locr_fail(eng, "svtr linear: channel mismatch", "");
+    hipError_t e = svtr_gemm_launch(p, eng->svtr.dtype, st);
+    return e == hipSuccess ? 0 : locr_fail(eng, "svtr_gemm", hipGetErrorString(e));
+}
+
 static int svtr_forward_sub(lumina_ocr* eng, const uint8_t* crops, const int* widths, int N, int* idx, float* prob, hipStream_t st) {
     eng->ws_off = 0;
     const bool dry = (eng->ws == nullptr) || crops == nullptr;
     SvtrModel& M = eng->svtr;
-    const int T = 80;
-    Tensor4 e1 = ws_tensor(eng, N, 16, 160, 32);
-    if (!dry && e1.p) {
-        StemParams sp{};
-        sp.x = crops; sp.wpk = M.pe1_wpk; sp.bias = M.pe1_bias; sp.y = e1.p; sp.valid_w_per_img = widths;
-        sp.N = N; sp.H = 32; sp.W = 320; sp.valid_h = 32; sp.valid_w = 320; sp.Ho = 16; sp.Wo = 160; sp.Cout_store = 32;
-        sp.act = ACT_GELU;
-        for (int c = 0; c < 3; ++c) { sp.scale[c] = 2.0f / 255.0f; sp.shift[c] = -1.0f; }
-        hipError_t e = stem_conv_launch(sp, st);
-        if (e != hipSuccess) return locr_fail(eng, "svtr.pe1", hipGetErrorString(e));
-    }
-    Tensor4 e2 = ws_tensor(eng, N, 8, 80, 64);
-    RUN(eng_run_conv(eng, M.pe2, e1, &e2, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st));
-    Tensor4 x = ws_tensor(eng, N, 8, 80, 64);
-    LAUNCH("svtr.pos", svtr_add_pos_launch(e2.p, M.pos, x.p, N, 640, 64, st));
+    const int T = 80, dt = M.dtype, d0 = M.dims[0];
+    Tensor4 patches = ws_tensor(eng, N, 16, 160, 32);
+    LAUNCH("svtr.im2col", svtr_im2col_launch(crops, widths, patches.p, N, dt, st));
+    Tensor4 e1 = ws_tensor(eng, N, 16, 160, d0 / 2);
+    RUN(run_linear(eng, M.pe1, patches, &e1, nullptr, 0, 0, 1, 1, 1, 1, 1, 1, dry, st));
+    Tensor4 x = ws_tensor(eng, N, 8, 80, d0);   // patch embedding 2 (3x3 / s2, GELU, rounded) + positional embedding (rounded again)
+    RUN(run_linear(eng, M.pe2, e1, &x, M.pos, 640, 1, 16, 160, 8, 80, 2, 2, dry, st));
     tap(eng, "svtr.embed", x);
-    int stage_dim = 64;
+    int stage = 0;
     for (size_t bi = 0; bi < M.blocks.size(); ++bi) {
         SvtrBlock& B = M.blocks[bi];
-        if (B.dim != stage_dim) {   // height merging: 3x3 conv at stride 1, LayerNorm of the even rows
-            const int s = stage_dim == 64 ? 0 : 1;
-            Tensor4 c1 = ws_tensor(eng, N, x.h, x.w, B.dim);
-            RUN(eng_run_conv(eng, M.sub[s], x, &c1, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st));
-            Tensor4 y = ws_tensor(eng, N, x.h / 2, x.w, B.dim);
-            LAUNCH("svtr.sub.ln", svtr_layernorm_launch(c1.p, M.sub_g[s], M.sub_b[s], y.p, N, x.h, x.h / 2, x.w, B.dim, 2, 1e-6f, st));
-            tap(eng, s == 0 ? "svtr.sub0" : "svtr.sub1", y);
-            x = y; stage_dim = B.dim;
+        const int want_stage = (int)bi < M.depths[0] ? 0 : ((int)bi < M.depths[0] + M.depths[1] ? 1 : 2);
+        if (want_stage != stage) {
+            // height merging: 3x3 conv, stride (2, 1), + LayerNorm (fused epilogue)
+            Tensor4 y = ws_tensor(eng, N, x.h / 2, x.w, M.dims[stage + 1]);
+            RUN(run_linear(eng, M.sub[stage], x, &y, nullptr, 0, 0, x.h, x.w, x.h / 2, x.w, 2, 1, dry, st));
+            tap(eng, stage == 0 ? "svtr.sub0" : "svtr.sub1", y);
+            x = y; ++stage;
         }
         const int Tk = x.h * x.w, c = B.dim;
         Tensor4 qkv = ws_tensor(eng, N, x.h, x.w, 3 * c);
-        RUN(eng_run_conv(eng, B.qkv, x, &qkv, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
+        RUN(run_linear(eng, B.qkv, x, &qkv, nullptr, 0, 0, 1, 1, 1, 1, 1, 1, dry, st));
         Tensor4 att = ws_tensor(eng, N, x.h, x.w, c);
-        LAUNCH("svtr.attn", svtr_attention_launch(qkv.p, att.p, N, Tk, B.heads, B.gh, B.gw, B.local ? 1 : 0, st));
-        Tensor4 pr = ws_tensor(eng, N, x.h, x.w, c);
-        RUN(eng_run_conv(eng, B.proj, att, &pr, &x, 0, OUT_NORMAL, 0, 0, 0, true, st));
+        LAUNCH("svtr.attn", svtr_attention_launch(qkv.p, att.p, N, Tk, B.heads, B.gh, B.gw, B.local ? 1 : 0, dt, st));
         Tensor4 x1 = ws_tensor(eng, N, x.h, x.w, c);
-        LAUNCH("svtr.ln1", svtr_layernorm_launch(pr.p, B.ln1g, B.ln1b, x1.p, N, x.h, x.h, x.w, c, 1, 1e-6f, st));
+        RUN(run_linear(eng, B.proj, att, &x1, x.p, 0, 0, 1, 1, 1, 1, 1, 1, dry, st));        // + residual, LayerNorm 1
         Tensor4 f1 = ws_tensor(eng, N, x.h, x.w, 4 * c);
-        RUN(eng_run_conv(eng, B.fc1, x1, &f1, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
-        Tensor4 f2 = ws_tensor(eng, N, x.h, x.w, c);
-        RUN(eng_run_conv(eng, B.fc2, f1, &f2, &x1, 0, OUT_NORMAL, 0, 0, 0, true, st));
+        RUN(run_linear(eng, B.fc1, x1, &f1, nullptr, 0, 0, 1, 1, 1, 1, 1, 1, dry, st));
         Tensor4 x2 = ws_tensor(eng, N, x.h, x.w, c);
-        LAUNCH("svtr.ln2", svtr_layernorm_launch(f2.p, B.ln2g, B.ln2b, x2.p, N, x.h, x.h, x.w, c, 1, 1e-6f, st));
+        RUN(run_linear(eng, B.fc2, f1, &x2, x1.p, 0, 0, 1, 1, 1, 1, 1, 1, dry, st));         // + residual, LayerNorm 2
         tap(eng, ("svtr.b" + std::to_string(bi)).c_str(), x2);
         x = x2;
     }
-    Tensor4 pooled = ws_tensor(eng, N, 1, T, 256);
-    LAUNCH("svtr.pool", svtr_rowmean_launch(x.p, pooled.p, N, x.h, x.w, 256, st));
-    Tensor4 seq = ws_tensor(eng, N, 1, T, 192);
-    RUN(eng_run_conv(eng, M.last, pooled, &seq, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
+    Tensor4 pooled = ws_tensor(eng, N, 1, T, M.dims[2]);
+    LAUNCH("svtr.pool", svtr_rowmean_launch(x.p, pooled.p, N, x.h, x.w, M.dims[2], dt, st));
+    Tensor4 seq = ws_tensor(eng, N, 1, T, M.out_ch);
+    RUN(run_linear(eng, M.last, pooled, &seq, nullptr, 0, 0, 1, 1, 1, 1, 1, 1, dry, st));
     tap(eng, "svtr.seq", seq);
     if (!dry) {
         CtcFcParams cp{};
         cp.seq = seq.p; cp.wpk = M.ctc_wpk; cp.bias = M.ctc_bias; cp.out_idx = idx; cp.out_prob = prob;
-        cp.M = N * T; cp.K = 192; cp.C = M.num_classes; cp.ntiles = M.ctc_ntiles;
+        cp.M = N * T; cp.K = M.out_ch; cp.C = M.num_classes; cp.ntiles = M.ctc_ntiles; cp.f16 = dt;
         hipError_t e = ctc_fc_argmax_launch(cp, st);
         if (e != hipSuccess) return locr_fail(eng, "svtr ctc_fc_argmax", hipGetErrorString(e));
     }
@@ -782,7 +835,7 @@ int eng_svtr_forward(lumina_ocr* eng, const uint8_t* crops, const int* widths, i
     if (!eng->svtr.loaded) return locr_fail(eng, "svtr_forward", "SVTR weights not loaded");
     if (N <= 0) return 0;
     HIPCHK(hipSetDevice(eng->device));
-    int sb = eng->rec_sub_batch / 2;   // ~3 MB of activations per crop
+    int sb = eng->rec_sub_batch / (eng->svtr.dims[2] > 256 ? 4 : 2);   // ~3 MB (Tiny) / ~7 MB (Base) of activations per crop
     if (sb < 1) sb = 1;
     if (sb > N) sb = N;
     uint8_t* keep = eng->ws; eng->ws = nullptr;

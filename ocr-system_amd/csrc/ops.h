@@ -29,6 +29,7 @@ struct CtcFcParams {
     float* part_max; int* part_idx; float* part_sum;  // [M][ntiles]
     int* out_idx; float* out_prob;                    // [M]
     int M, K, C, ntiles;
+    int f16;   // sequence and packed weights are fp16 (SVTR fp16 mode) instead of bf16
 };
 size_t ctc_packed_weight_elems(int C, int K);
 void pack_ctc_weights(const bf16_t* w /*[C][K]*/, int C, int K, bf16_t* out);

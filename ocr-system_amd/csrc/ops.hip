@@ -2,6 +2,8 @@
 // No reference counterpart exists; semantics are defined by oracle/nets.py.
 #include "ops.h"
 
+#include <type_traits>
+
 #include <cstdlib>
 
 namespace {
@@ -270,6 +272,8 @@ constexpr int CT_MT = 1, CT_NT = 2;  // per wave: CT_MT x 32 rows, CT_NT x 32 cl
 constexpr int CT_ROWS = 4 * 32 * CT_MT, CT_BN = 32 * CT_NT, CT_KMAX = 192, CT_WIT = CT_BN * (CT_KMAX / 8) / 256;
 constexpr int CT_PLANE_A = CT_ROWS + 4;  // entries, == 4 (mod 16)
 
+typedef _Float16 ctc_f16x8_t __attribute__((ext_vector_type(8)));
+template <int DT>   // storage type of the sequence and the weights: 0 bf16, 1 fp16 (SVTR fp16 mode)
 __global__ __launch_bounds__(256, 2) void ctc_fc_argmax_kernel(const CtcFcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int npl = p.K >> 3;
@@ -321,18 +325,21 @@ __global__ __launch_bounds__(256, 2) void ctc_fc_argmax_kernel(const CtcFcParams
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
         for (int kc = 0; kc < ksteps; ++kc) {
-            bf16x8_t bfr[CT_MT], afr[CT_NT];
+            typedef typename std::conditional<DT == 1, ctc_f16x8_t, bf16x8_t>::type frag_t;
+            frag_t bfr[CT_MT], afr[CT_NT];
 #pragma unroll
             for (int mt = 0; mt < CT_MT; ++mt)
-                bfr[mt] = *reinterpret_cast<const bf16x8_t*>(sA + ((size_t)(2 * kc + h) * CT_PLANE_A + wave * (32 * CT_MT) + mt * 32 + r) * 16);
+                bfr[mt] = *reinterpret_cast<const frag_t*>(sA + ((size_t)(2 * kc + h) * CT_PLANE_A + wave * (32 * CT_MT) + mt * 32 + r) * 16);
 #pragma unroll
             for (int nt = 0; nt < CT_NT; ++nt)
-                afr[nt] = *reinterpret_cast<const bf16x8_t*>(sW + ((size_t)(2 * kc + h) * CT_BN + nt * 32 + r) * 16);
+                afr[nt] = *reinterpret_cast<const frag_t*>(sW + ((size_t)(2 * kc + h) * CT_BN + nt * 32 + r) * 16);
 #pragma unroll
             for (int mt = 0; mt < CT_MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < CT_NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[nt], bfr[mt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < CT_NT; ++nt) {
+                    if constexpr (DT == 1) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[nt], bfr[mt], acc[mt][nt], 0, 0, 0);
+                    else acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[nt], bfr[mt], acc[mt][nt], 0, 0, 0);
+                }
         }
         // per-tile reduction over this lane's 64 classes, then the partner half-wave, then the running state
         const float* bt = p.bias + tile * CT_BN;
@@ -470,8 +477,13 @@ void pack_ctc_weights(const bf16_t* w, int C, int K, bf16_t* out) {
 hipError_t ctc_fc_argmax_launch(const CtcFcParams& p, hipStream_t st) {
     if (p.K % 16 != 0 || p.K > CT_KMAX) return hipErrorInvalidValue;
     const size_t lds = (size_t)(p.K / 8) * (CT_PLANE_A + CT_BN) * 16;
-    { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(ctc_fc_argmax_kernel), 160 * 1024); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(ctc_fc_argmax_kernel, dim3((p.M + CT_ROWS - 1) / CT_ROWS), dim3(256), lds, st, p);
+    if (p.f16) {
+        { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(ctc_fc_argmax_kernel<1>), 160 * 1024); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(ctc_fc_argmax_kernel<1>, dim3((p.M + CT_ROWS - 1) / CT_ROWS), dim3(256), lds, st, p);
+    } else {
+        { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(ctc_fc_argmax_kernel<0>), 160 * 1024); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(ctc_fc_argmax_kernel<0>, dim3((p.M + CT_ROWS - 1) / CT_ROWS), dim3(256), lds, st, p);
+    }
     return hipGetLastError();
 }
 

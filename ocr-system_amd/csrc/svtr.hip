@@ -1,201 +1,261 @@
-// SVTR-Tiny recogniser glue kernels (the linear layers and convolutions run on conv_mfma.hip / stem_conv.hip):
-// positional-embedding add, LayerNorm (with the row selection of the stride-(2,1) merging conv and the final row pooling), and
-// the mixing blocks' attention core (local 7 x 11 window or global).  Arithmetic definition: oracle/nets.py svtr_backbone —
-// bf16 stored tensors, fp32 inside (scores, soft-max, probability-weighted sum, mean / variance), one rounding per stored tensor.
-// No reference counterpart exists (BASELINE configs[4] names the model; SURVEY.md §0.5: nothing of it ships): parity unpinned.
+// SVTR recogniser (Tiny / Base: dimensions come from the weight blob) on gfx950, in bf16 or fp16 (BASELINE configs[4]: "SVTR-base
+// multilingual, fp16 MFMA").  No reference counterpart exists (the model is named by BASELINE; SURVEY.md §0.5: no code, weights
+// or dictionary ship): parity unpinned, arithmetic definition = oracle/nets.py svtr_backbone — stored tensors 16-bit (bf16 or
+// fp16), fp32 inside (accumulation, soft-max, mean / variance, GELU), one rounding per stored tensor.
+//
+// Four kernels, each templated on the storage type:
+//   svtr_im2col     u8 crop -> normalised 3x3/s2 patches [N*16*160][32] (27 taps + 5 zeros): the first conv becomes a GEMM
+//   svtr_gemm       every linear layer AND every convolution of the model: Y = epi(gather(X) W^T + b).  128 token rows x
+//                   32*NT output channels per work-group, K in 32-deep steps through a 2-deep LDS ring filled by LDS-DMA
+//                   (global_load_lds 16 B, slices XOR-swizzled on the source side: conflict-free ds_read_b128), 32x32x16 MFMA
+//                   with the weights as the A operand (a lane ends up with 4 consecutive channels of ONE token per quad).
+//                   gather = 3x3 taps with stride (sh, sw) and zero padding over a token grid (taps = 1: plain GEMM).
+//                   epilogue in registers: + bias, + residual (a row of the same tensor shape, or a row of a [res_mod][N] table:
+//                   the positional embedding), activation, rounding, and optionally LayerNorm over the N channels of the token
+//                   (a wave owns complete token rows: the row statistics are a lane-local sum + one cross-half shuffle) — the
+//                   un-normalised tensor never goes to memory, there is no separate LayerNorm pass.
+//   svtr_attn       flash-attention form on the matrix cores, head dimension 32; K and V^T of a head in LDS; LOCAL mixing blocks
+//                   use 4x8-token query tiles whose 7x11 windows cover <= 10 key rows x 21 key columns: one 32-key tile per key
+//                   row instead of every key of the grid.
+//   svtr_rowmean    mean over the remaining token rows.
+// The CTC head (ops.hip ctc_fc_argmax, templated on the same storage type) follows.
 #include "svtr.h"
 
 #include <cstdlib>
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+template <int DT> struct Num;
+template <> struct Num<0> {   // bf16
+    typedef bf16x8_t frag_t;
+    static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+    static __device__ __forceinline__ float one(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+    static __device__ __forceinline__ uint32_t pack(float a, float b) { return pack_bf16x2(a, b); }
+    static __device__ __forceinline__ uint16_t cvt(float a) { return f32_to_bf16(a); }
+    static __device__ __forceinline__ f32x16_t mfma(frag_t a, frag_t b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Num<1> {   // fp16
+    typedef f16x8_t frag_t;
+    static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+    static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+    static __device__ __forceinline__ float one(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+    static __device__ __forceinline__ uint32_t pack(float a, float b) { f16x2_t v; v[0] = (_Float16)a; v[1] = (_Float16)b; return __builtin_bit_cast(uint32_t, v); }   // round to nearest even
+    static __device__ __forceinline__ uint16_t cvt(float a) { return __builtin_bit_cast(uint16_t, (_Float16)a); }
+    static __device__ __forceinline__ f32x16_t mfma(frag_t a, frag_t b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+inline int grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g > 256 * 32 ? 256 * 32 : (g ? g : 1));
 }
 
-// y[n, t, c] = bf16(x[n, t, c] + pos[t, c])
-__global__ void svtr_add_pos_kernel(const bf16_t* x, const bf16_t* pos, bf16_t* y, size_t total8, int tc8) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
-        const uint4 a = reinterpret_cast<const uint4*>(x)[i], b = reinterpret_cast<const uint4*>(pos)[i % tc8];
-        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
-        uint32_t o[4];
+// ------------------------------------------------------------------------------------------------ im2col of the first conv
+// crops u8 [N][32][320][3] -> patches [N][16][160][32]: element (kh * 3 + kw) * 3 + c = xn(2 oy + kh - 1, 2 ox + kw - 1, c), xn = T(u8 * (2 / 255) - 1)
+// inside the crop's valid width, 0 outside the image / beyond the valid width (zero padding in normalised space); 27..31 = 0.
+template <int DT>
+__global__ __launch_bounds__(256) void svtr_im2col_kernel(const uint8_t* crops, const int* widths, uint16_t* out, int N) {
+    const size_t total = (size_t)N * 16 * 160;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ox = (int)(i % 160), oy = (int)((i / 160) % 16), n = (int)(i / 2560);
+        const int vw = widths ? widths[n] : 320;
+        const uint8_t* img = crops + (size_t)n * 32 * 320 * 3;
+        uint16_t v[32];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            o[j] = pack_bf16x2(__uint_as_float(aw[j] << 16) + __uint_as_float(bw[j] << 16), __uint_as_float(aw[j] & 0xFFFF0000u) + __uint_as_float(bw[j] & 0xFFFF0000u));
-        reinterpret_cast<uint4*>(y)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+        for (int k = 0; k < 32; ++k) v[k] = 0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iy = 2 * oy + kh - 1, ix = 2 * ox + kw - 1;
+                if (iy < 0 || iy >= 32 || ix < 0 || ix >= vw) continue;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[(kh * 3 + kw) * 3 + c] = Num<DT>::cvt(__fadd_rn(__fmul_rn((float)img[(iy * 320 + ix) * 3 + c], 2.0f / 255.0f), -1.0f));
+            }
+        uint4* dst = reinterpret_cast<uint4*>(out + i * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            dst[q] = make_uint4(v[8 * q] | ((uint32_t)v[8 * q + 1] << 16), v[8 * q + 2] | ((uint32_t)v[8 * q + 3] << 16), v[8 * q + 4] | ((uint32_t)v[8 * q + 5] << 16),
+                                v[8 * q + 6] | ((uint32_t)v[8 * q + 7] << 16));
     }
 }
 
-// LayerNorm over C, one wave per output token.  Input token of output (n, oy, x) is (n, oy * row_step, x) of an [N, Hin, W, C]
-// tensor (row_step = 2: the stride-(2,1) merging conv was computed at stride 1 and only its even rows are kept).
-template <int CPL>  // channels per lane: C = 64 * CPL
-__global__ __launch_bounds__(256) void svtr_layernorm_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int N, int Hin, int Hout, int W,
-                                                             int row_step, float eps) {
-    constexpr int C = 64 * CPL;
-    const int lane = threadIdx.x & 63;
-    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tok >= (long long)N * Hout * W) return;
-    const int xw = (int)(tok % W);
-    const long long t2 = tok / W;
-    const int oy = (int)(t2 % Hout), n = (int)(t2 / Hout);
-    const bf16_t* src = x + (((size_t)n * Hin + (size_t)oy * row_step) * W + xw) * C + lane * CPL;
-    float v[CPL];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) v[j] = bf16_to_f32(src[j]);
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) s += v[j];
-    const float mu = wave_sum(s) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) { const float d = v[j] - mu; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-    bf16_t* dst = y + (size_t)tok * C + lane * CPL;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) dst[j] = f32_to_bf16((v[j] - mu) * rstd * gamma[lane * CPL + j] + beta[lane * CPL + j]);
-}
+// ------------------------------------------------------------------------------------------------ GEMM with gather + fused epilogue
+constexpr int G_BM = 128, G_BK = 32;
+template <int NT> struct GCfg {
+    static constexpr int BN = 32 * NT;
+    static constexpr int X_BYTES = G_BM * G_BK * 2, W_BYTES = BN * G_BK * 2, BUF = X_BYTES + W_BYTES;
+    static constexpr int LDS = 2 * BUF;
+    static constexpr int XIT = (G_BM * 4) / 256, WIT = (BN * 4 + 255) / 256;   // 16-byte pieces per thread and stage
+};
 
-// y[n, x, c] = bf16(mean over the H rows of x[n, :, x, c])   (H = 2 at the end of the backbone)
-__global__ void svtr_rowmean_kernel(const bf16_t* x, bf16_t* y, int N, int H, int W, int C) {
-    const size_t total = (size_t)N * W * C;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const size_t t = i / C;
-        const int xw = (int)(t % W), n = (int)(t / W);
-        float s = 0.f;
-        for (int r = 0; r < H; ++r) s += bf16_to_f32(x[(((size_t)n * H + r) * W + xw) * C + c]);
-        y[i] = f32_to_bf16(s / (float)H);
-    }
-}
-
-// Attention core, head dimension 32.  One workgroup = 64 queries of one (crop, head); the head's K ([T][32], expanded to fp32 so
-// that the score loop has no unpacking) and V ([T][32] bf16) are staged in LDS; thread (q, part) walks every AT_PARTS-th key of the
-// query's key set (the 7 x 11 window for local blocks, all T keys otherwise) ONCE with an online soft-max (running maximum,
-// rescaled sum and weighted V accumulator); the AT_PARTS partial soft-maxes of a query are merged through LDS in a fixed order.  fp32 throughout,
-// one bf16 rounding of the output.
-constexpr int AT_HD = 32, AT_Q = 64, AT_RED = 36;   // floats per (part, query) in the merge buffer: m, l, o[32] (+pad)
-constexpr int AT_PARTS = 8;                          // threads per query (512-thread workgroups: two waves per SIMD at one workgroup per CU)
-__global__ __launch_bounds__(64 * AT_PARTS) void svtr_attn_kernel(const bf16_t* qkv, bf16_t* out, int T, int heads, int gh, int gw, int local) {
+template <int DT, int NT, bool LN>
+__global__ __launch_bounds__(256, (NT <= 6 ? 2 : 1)) void svtr_gemm_kernel(const SvtrGemmParams p) {
+    using C = GCfg<NT>;
+    using NM = Num<DT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* sK = reinterpret_cast<float*>(smem);                                  // [T][32] fp32
-    bf16_t* sV = reinterpret_cast<bf16_t*>(smem + (size_t)T * AT_HD * 4);         // [T][32] bf16
-    float* red = reinterpret_cast<float*>(smem);                                 // aliases sK after the key loop
-    const int tid = threadIdx.x, ql = tid & 63, part = tid >> 6;
-    const int n = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * AT_Q;
-    const int C = heads * AT_HD;
-    const bf16_t* base = qkv + (size_t)n * T * 3 * C;
-    for (int i = tid; i < T * 4; i += 64 * AT_PARTS) {   // token t, 8-channel slice s4
-        const int t = i >> 2, s4 = i & 3;
-        const uint4 kv = *reinterpret_cast<const uint4*>(base + ((size_t)t * 3 + 1) * C + hd * AT_HD + s4 * 8);
-        reinterpret_cast<uint4*>(sV)[i] = *reinterpret_cast<const uint4*>(base + ((size_t)t * 3 + 2) * C + hd * AT_HD + s4 * 8);
-        float4* kd = reinterpret_cast<float4*>(sK + (size_t)t * AT_HD + s4 * 8);
-        kd[0] = make_float4(__uint_as_float(kv.x << 16), __uint_as_float(kv.x & 0xFFFF0000u), __uint_as_float(kv.y << 16), __uint_as_float(kv.y & 0xFFFF0000u));
-        kd[1] = make_float4(__uint_as_float(kv.z << 16), __uint_as_float(kv.z & 0xFFFF0000u), __uint_as_float(kv.w << 16), __uint_as_float(kv.w & 0xFFFF0000u));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * G_BM, n0 = blockIdx.y * C::BN;
+    const int nk = p.K / G_BK, cin_blocks = p.Cin / G_BK;   // K = taps * Cin; a 32-deep K block lies inside one tap
+
+    // ---- staging descriptors.  LDS image of a stage: X rows [128][4 slices of 16 B] then W rows [BN][4 slices]; slot s of row q
+    // holds k-slice s ^ ((q >> 2) & 3): 16 consecutive rows cover the 16 slots of the 256-byte bank row exactly once.
+    int x_row[C::XIT], x_sl[C::XIT];       // token row of this thread's X piece (relative to m0) and its k-slice
+    int x_n[C::XIT], x_oy[C::XIT], x_ox[C::XIT];
+#pragma unroll
+    for (int it = 0; it < C::XIT; ++it) {
+        const int i = tid + 256 * it, q = i >> 2, s = (i & 3) ^ ((q >> 2) & 3);
+        x_row[it] = q; x_sl[it] = s;
+        int m = m0 + q;
+        if (m >= p.M) m = p.M - 1;
+        x_n[it] = m / p.Tout;
+        const int t = m - x_n[it] * p.Tout;
+        x_oy[it] = t / p.Wout; x_ox[it] = t - x_oy[it] * p.Wout;
     }
-    const int qt = min(q0 + ql, T - 1);
-    float q[AT_HD];
-    {
-        const uint4* qp = reinterpret_cast<const uint4*>(base + (size_t)qt * 3 * C + hd * AT_HD);
+    const uint16_t* wt = p.w + (size_t)n0 * p.K;
+    auto stage = [&](int kb, int buf) {
+        const int tap = kb / cin_blocks, c0 = (kb - tap * cin_blocks) * G_BK;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        unsigned char* dst = smem + buf * C::BUF;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const uint4 v = qp[s4];
-            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { q[s4 * 8 + 2 * j] = __uint_as_float(w4[j] << 16); q[s4 * 8 + 2 * j + 1] = __uint_as_float(w4[j] & 0xFFFF0000u); }
+        for (int it = 0; it < C::XIT; ++it) {
+            const int i = tid + 256 * it;
+            const uint16_t* src = p.zeros;
+            if (p.taps == 1) src = p.x + (size_t)min(m0 + x_row[it], p.M - 1) * p.Cin + c0 + x_sl[it] * 8;
+            else {
+                const int iy = x_oy[it] * p.sh + kh - 1, ix = x_ox[it] * p.sw + kw - 1;
+                if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) src = p.x + ((size_t)x_n[it] * p.Hin * p.Win + (size_t)iy * p.Win + ix) * p.Cin + c0 + x_sl[it] * 8;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + (i - lane) * 16), 16, 0, 0);
         }
-    }
-    __syncthreads();
-    const float scale = 0.17677669529663687f;  // 32^-0.5
-    const int qy = qt / gw, qx = qt - qy * gw;
-    const int nkeys = local ? 77 : T;
-    float m = -3.0e38f, l = 0.f, o[AT_HD];
 #pragma unroll
-    for (int d = 0; d < AT_HD; ++d) o[d] = 0.f;
-    for (int i = part; i < nkeys; i += AT_PARTS) {
-        int key = i;
-        if (local) {
-            const int wy = i / 11, ky = qy - 3 + wy, kx = qx - 5 + (i - wy * 11);
-            key = (ky >= 0 && ky < gh && kx >= 0 && kx < gw) ? ky * gw + kx : -1;
+        for (int it = 0; it < C::WIT; ++it) {
+            const int i = tid + 256 * it;
+            if (C::BN * 4 % 256 == 0 || i < C::BN * 4) {
+                const int q = i >> 2, s = (i & 3) ^ ((q >> 2) & 3);
+                const uint16_t* src = wt + (size_t)q * p.K + kb * G_BK + s * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + C::X_BYTES + (i - lane) * 16), 16, 0, 0);
+            }
         }
-        if (key < 0) continue;
-        const float4* kp = reinterpret_cast<const float4*>(sK + (size_t)key * AT_HD);
-        float sc = 0.f;
+    };
+    static_assert((C::BN * 4) % 64 == 0, "weight pieces split on wave boundaries");
+
+    f32x16_t acc[NT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 kk = kp[j];
-            sc = __builtin_fmaf(q[4 * j], kk.x, sc); sc = __builtin_fmaf(q[4 * j + 1], kk.y, sc);
-            sc = __builtin_fmaf(q[4 * j + 2], kk.z, sc); sc = __builtin_fmaf(q[4 * j + 3], kk.w, sc);
-        }
-        sc *= scale;
-        if (sc > m) {   // new running maximum: rescale what has been accumulated (exp(-huge) = 0 on the first key)
-            const float corr = expf(m - sc);
-            l *= corr;
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int d = 0; d < AT_HD; ++d) o[d] *= corr;
-            m = sc;
-        }
-        const float pr = expf(sc - m);
-        l += pr;
-        const uint4* vp = reinterpret_cast<const uint4*>(sV + (size_t)key * AT_HD);
+        for (int j = 0; j < 16; ++j) acc[nt][j] = 0.f;
+    // fragment read offsets: row q, k-slice (2 ks + h) -> slot (2 ks + h) ^ ((q >> 2) & 3)
+    const int xq = wave * 32 + r;
+    const int xoff = xq * 64, xsw = (xq >> 2) & 3;
+    const int wsw = (r >> 2) & 3;   // weight row q = nt * 32 + r: (q >> 2) & 3 == (r >> 2) & 3
+
+    stage(0, 0);
+    for (int kb = 0; kb < nk; ++kb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // stage kb has landed for every wave; buffer (kb + 1) & 1 is free again
+        if (kb + 1 < nk) stage(kb + 1, (kb + 1) & 1);
+        const unsigned char* buf = smem + (kb & 1) * C::BUF;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const uint4 v = vp[s4];
-            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+        for (int ks = 0; ks < 2; ++ks) {
+            const typename NM::frag_t xb = *reinterpret_cast<const typename NM::frag_t*>(buf + xoff + (((2 * ks + h) ^ xsw) << 4));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[s4 * 8 + 2 * j] = __builtin_fmaf(pr, __uint_as_float(w4[j] << 16), o[s4 * 8 + 2 * j]);
-                o[s4 * 8 + 2 * j + 1] = __builtin_fmaf(pr, __uint_as_float(w4[j] & 0xFFFF0000u), o[s4 * 8 + 2 * j + 1]);
+            for (int nt = 0; nt < NT; ++nt) {
+                const typename NM::frag_t wa = *reinterpret_cast<const typename NM::frag_t*>(buf + C::X_BYTES + (nt * 32 + r) * 64 + (((2 * ks + h) ^ wsw) << 4));
+                acc[nt] = NM::mfma(wa, xb, acc[nt]);
             }
         }
     }
-    __syncthreads();   // every thread is done with sK: the merge buffer may overwrite it
-    float* mine = red + (part * 64 + ql) * AT_RED;
-    mine[0] = m; mine[1] = l;
+
+    // ---- epilogue: lane (token r, half h) holds channels n0 + nt * 32 + 8 g + 4 h + j (g, j in 0..3) of its token
+    const int m = m0 + wave * 32 + r;
+    const bool valid = m < p.M;
+    const int mc = valid ? m : p.M - 1;
+    const uint16_t* rrow = p.res ? p.res + (size_t)(p.res_mod ? mc % p.res_mod : mc) * p.N + n0 : nullptr;
+    float rsum = 0.f;
 #pragma unroll
-    for (int d = 0; d < AT_HD; ++d) mine[2 + d] = o[d];
-    __syncthreads();
-    if (part == 0 && q0 + ql < T) {   // merge the partial soft-maxes in a fixed order
-        float mt = red[ql * AT_RED];
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int pp = 1; pp < AT_PARTS; ++pp) mt = fmaxf(mt, red[(pp * 64 + ql) * AT_RED]);
-        float f[AT_PARTS], lt = 0.f;
+        for (int g = 0; g < 4; ++g) {
+            const int c = nt * 32 + 8 * g + 4 * h;
+            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n0 + c);
+            float v[4] = {acc[nt][4 * g] + b4.x, acc[nt][4 * g + 1] + b4.y, acc[nt][4 * g + 2] + b4.z, acc[nt][4 * g + 3] + b4.w};
+            float rv4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (rrow) {
+                const uint2 rv = *reinterpret_cast<const uint2*>(rrow + c);
+                rv4[0] = NM::lo(rv.x); rv4[1] = NM::hi(rv.x); rv4[2] = NM::lo(rv.y); rv4[3] = NM::hi(rv.y);
+                if (!p.res_post) { v[0] += rv4[0]; v[1] += rv4[1]; v[2] += rv4[2]; v[3] += rv4[3]; }
+            }
 #pragma unroll
-        for (int pp = 0; pp < AT_PARTS; ++pp) { f[pp] = expf(red[(pp * 64 + ql) * AT_RED] - mt); lt += red[(pp * 64 + ql) * AT_RED + 1] * f[pp]; }
-        const float inv = 1.0f / lt;
-        uint32_t w[16];
-#pragma unroll
-        for (int d = 0; d < AT_HD; d += 2) {
-            float a = 0.f, b2 = 0.f;
-#pragma unroll
-            for (int pp = 0; pp < AT_PARTS; ++pp) { a += red[(pp * 64 + ql) * AT_RED + 2 + d] * f[pp]; b2 += red[(pp * 64 + ql) * AT_RED + 3 + d] * f[pp]; }
-            w[d >> 1] = pack_bf16x2(a * inv, b2 * inv);
+            for (int j = 0; j < 4; ++j) {
+                float y = v[j];
+                if (p.act == ACT_GELU) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752f));
+                else if (p.act == ACT_HSWISH) y = y * fminf(fmaxf(y + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                if (rrow && p.res_post) y = NM::one(NM::cvt(y)) + rv4[j];   // the activation's output is a stored (rounded) tensor of the definition
+                if constexpr (LN) { y = NM::one(NM::cvt(y)); rsum += y; }   // the (un-stored) linear output is a 16-bit tensor in the definition
+                acc[nt][4 * g + j] = y;
+            }
         }
-        uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)n * T + q0 + ql) * C + hd * AT_HD);
+    if constexpr (LN) {   // LayerNorm over the token's N = 32 NT channels (this work-group holds all of them: gridDim.y == 1)
+        rsum += __shfl_xor(rsum, 32);
+        const float mu = rsum / (float)C::BN;
+        float q = 0.f;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) dst[s4] = make_uint4(w[4 * s4], w[4 * s4 + 1], w[4 * s4 + 2], w[4 * s4 + 3]);
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const float d = acc[nt][j] - mu; q += d * d; }
+        q += __shfl_xor(q, 32);
+        const float rstd = 1.0f / sqrtf(q / (float)C::BN + p.eps);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = nt * 32 + 8 * g + 4 * h;
+                const float4 ga = *reinterpret_cast<const float4*>(p.gamma + c), be = *reinterpret_cast<const float4*>(p.beta + c);
+                acc[nt][4 * g] = (acc[nt][4 * g] - mu) * rstd * ga.x + be.x; acc[nt][4 * g + 1] = (acc[nt][4 * g + 1] - mu) * rstd * ga.y + be.y;
+                acc[nt][4 * g + 2] = (acc[nt][4 * g + 2] - mu) * rstd * ga.z + be.z; acc[nt][4 * g + 3] = (acc[nt][4 * g + 3] - mu) * rstd * ga.w + be.w;
+            }
     }
+    // v_permlane32_swap trades quad g of the upper half-wave for quad g + 1 of the lower one: 16-byte pieces of 8 consecutive channels
+    uint16_t* yrow = p.y + (size_t)mc * p.N + n0 + 8 * h;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            const int g0 = 2 * gp, g1 = 2 * gp + 1;
+            const uint32_t q0x = NM::pack(acc[nt][4 * g0], acc[nt][4 * g0 + 1]), q0y = NM::pack(acc[nt][4 * g0 + 2], acc[nt][4 * g0 + 3]);
+            const uint32_t q1x = NM::pack(acc[nt][4 * g1], acc[nt][4 * g1 + 1]), q1y = NM::pack(acc[nt][4 * g1 + 2], acc[nt][4 * g1 + 3]);
+            const auto sx = __builtin_amdgcn_permlane32_swap(q0x, q1x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(q0y, q1y, false, false);
+            if (valid) *reinterpret_cast<uint4*>(yrow + nt * 32 + gp * 16) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
 }
 
-// Attention core on the matrix cores (flash-attention form, head dimension 32).  One workgroup = MA_W waves x 32 queries of one
-// (crop, head).  K ([T][32] bf16, rows padded to 80 B) and V TRANSPOSED ([32][T] bf16, rows padded) are staged in LDS once.
-// Per 32-key tile a wave computes S^T[key][query] = K Q^T with two 32x32x16 MFMAs (A = K rows from LDS, B = the wave's Q
-// rows, held in registers), masks the keys outside the 7 x 11 window (local blocks), updates the running maximum / sum of its
-// queries (a query's 32 scores live in 16 registers of lane q and 16 of lane q + 32: one cross-half shuffle per reduction),
-// converts P to bf16 (v_permlane32_swap turns the accumulator layout into the 8-consecutive-keys operand layout) and accumulates
-// O^T[d][query] += V^T P^T with two more MFMAs.  Soft-max statistics are fp32; P is rounded to bf16 for the second product.
-constexpr int MA_W = 8, MA_KP = 40;   // waves per workgroup; K row pitch in elements (80 B: conflict-free 16-byte fragment reads)
-__global__ __launch_bounds__(64 * MA_W) void svtr_attn_mfma_kernel(const bf16_t* qkv, bf16_t* out, int T, int heads, int gh, int gw, int local) {
+// ------------------------------------------------------------------------------------------------ attention
+// One work-group = MA_W waves x 32 queries of one (crop, head); K ([Tpad + 32][32], rows padded to 80 B) and V TRANSPOSED ([32][T + 40])
+// of the head are staged in LDS once.  Per 32-key tile a wave computes S^T[key][query] = K Q^T (two 32x32x16 MFMAs, A = K rows from
+// LDS, B = the wave's Q rows in registers), masks, updates the running maximum / sum of its queries (a query's 32 scores live in 16
+// registers of lane q and 16 of lane q + 32), converts P to the storage type (v_permlane32_swap turns the accumulator layout into
+// the 8-consecutive-keys operand layout) and accumulates O^T[d][query] += V^T P^T with two more MFMAs.
+// Global blocks: a wave's queries are 32 consecutive tokens, every key tile is visited.  Local blocks (7 x 11 window): a wave's
+// queries are a 4-row x 8-column patch of the token grid; their windows lie in key rows y0-3 .. y0+6 and key columns x0-5 .. x0+12,
+// i.e. inside ONE 32-key tile per key row starting at the 8-aligned column x0-8: <= 10 tiles instead of T / 32.
+constexpr int MA_W = 8, MA_KP = 40, AT_HD = 32;
+template <int DT>
+__global__ __launch_bounds__(64 * MA_W) void svtr_attn_kernel(const uint16_t* qkv, uint16_t* out, int T, int heads, int gh, int gw, int local) {
+    using NM = Num<DT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int vp = T + 8;                                   // V^T row pitch in elements ((2T + 16) B: odd multiple of 16 B mod 128)
-    bf16_t* sK = reinterpret_cast<bf16_t*>(smem);          // [Tpad][MA_KP]
-    const int Tpad = (T + 31) & ~31;
-    bf16_t* sVt = sK + (size_t)Tpad * MA_KP;               // [32][vp]
+    const int Tpad = ((T + 31) & ~31) + 32;                 // a local key tile may start up to 24 keys before a row end: readable padding
+    const int vp = Tpad + 8;                                // V^T row pitch in elements
+    uint16_t* sK = reinterpret_cast<uint16_t*>(smem);      // [Tpad][MA_KP]
+    uint16_t* sVt = sK + (size_t)Tpad * MA_KP;             // [32][vp]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int n = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * (32 * MA_W) + wave * 32;
+    const int n = blockIdx.z, hd = blockIdx.y, tile = blockIdx.x * MA_W + wave;
     const int C = heads * AT_HD;
-    const bf16_t* base = qkv + (size_t)n * T * 3 * C;
+    const uint16_t* base = qkv + (size_t)n * T * 3 * C;
     for (int i = tid; i < Tpad * 4; i += 64 * MA_W) {
         const int t = i >> 2, s4 = i & 3;
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
@@ -207,49 +267,50 @@ __global__ __launch_bounds__(64 * MA_W) void svtr_attn_mfma_kernel(const bf16_t*
         const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            sVt[(size_t)(s4 * 8 + 2 * j) * vp + t] = (bf16_t)(w4[j] & 0xffffu);
-            sVt[(size_t)(s4 * 8 + 2 * j + 1) * vp + t] = (bf16_t)(w4[j] >> 16);
+            sVt[(size_t)(s4 * 8 + 2 * j) * vp + t] = (uint16_t)(w4[j] & 0xffffu);
+            sVt[(size_t)(s4 * 8 + 2 * j + 1) * vp + t] = (uint16_t)(w4[j] >> 16);
         }
     }
-    // the wave's Q rows as the MFMA B operand: lane (r = query, h) holds d = 16*ks + 8*h .. +7
-    const int qt = min(q0 + r, T - 1);
-    bf16x8_t qf[2];
+    // this lane's query token
+    const int tiles_x = gw / 8;
+    const int y0 = local ? (tile / tiles_x) * 4 : 0, x0 = local ? (tile % tiles_x) * 8 : 0;
+    const int qy = local ? y0 + (r >> 3) : 0, qx = local ? x0 + (r & 7) : 0;
+    const int qraw = local ? qy * gw + qx : tile * 32 + r;
+    const bool qvalid = local ? (qy < gh) : (qraw < T);
+    const int qt = qvalid ? qraw : T - 1;
+    typename NM::frag_t qf[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(base + (size_t)qt * 3 * C + hd * AT_HD + ks * 16 + h * 8);
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const typename NM::frag_t*>(base + (size_t)qt * 3 * C + hd * AT_HD + ks * 16 + h * 8);
     __syncthreads();
-    if (q0 >= T) return;
-    const float scale = 0.17677669529663687f;
-    const int qy = qt / gw, qx = qt - qy * gw;
-    const int qy_lo = q0 / gw, qy_hi = min(q0 + 31, T - 1) / gw;
+    if (local ? (y0 >= gh) : (tile * 32 >= T)) return;
+    const float scale = 0.17677669529663687f;   // 32^-0.5
     float m = -3.0e38f, l = 0.f;
     f32x16_t o;
 #pragma unroll
     for (int j = 0; j < 16; ++j) o[j] = 0.f;
-    for (int k0 = 0; k0 < Tpad; k0 += 32) {
-        if (local) {   // whole key tile outside the row band of this query tile: nothing to add
-            const int ky_lo = k0 / gw, ky_hi = min(k0 + 31, T - 1) / gw;
-            if (ky_hi < qy_lo - 3 || ky_lo > qy_hi + 3) continue;
-        }
+    // key tiles: (first key, number of keys that count) — global: every 32-key tile; local: one tile per key row of the patch's window
+    const int kx_lo = local ? max(x0 - 8, 0) : 0, kx_n = local ? min(gw, x0 + 13) - kx_lo : 0;   // columns [kx_lo, kx_lo + kx_n), kx_n <= 21
+    const int ky_lo = local ? max(y0 - 3, 0) : 0, ky_hi = local ? min(gh - 1, y0 + 6) : 0;
+    const int ntiles = local ? ky_hi - ky_lo + 1 : (T + 31) / 32;
+    for (int it = 0; it < ntiles; ++it) {
+        const int k0 = local ? (ky_lo + it) * gw + kx_lo : it * 32;
+        const int kcount = local ? kx_n : min(32, T - k0);
         f32x16_t sc;
 #pragma unroll
         for (int j = 0; j < 16; ++j) sc[j] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + (size_t)(k0 + r) * MA_KP + ks * 16 + h * 8);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
+            const typename NM::frag_t kf = *reinterpret_cast<const typename NM::frag_t*>(sK + (size_t)(k0 + r) * MA_KP + ks * 16 + h * 8);
+            sc = NM::mfma(kf, qf[ks], sc);
         }
         // lane (query = r): register j is key k0 + (j & 3) + 8 * (j >> 2) + 4 * h
         float tmax = -3.0e38f;
-        const int ky0 = k0 / gw, kx0 = k0 - ky0 * gw;   // grid position of the tile's first key (a tile of 32 wraps at most once: gw >= 32)
+        const int ky = ky_lo + it;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int off = (j & 3) + 8 * (j >> 2) + 4 * h;
-            bool ok = k0 + off < T;
-            if (local) {
-                int kx = kx0 + off, ky = ky0;
-                if (kx >= gw) { kx -= gw; ++ky; }
-                ok = ok && ky >= qy - 3 && ky <= qy + 3 && kx >= qx - 5 && kx <= qx + 5;
-            }
+            bool ok = off < kcount;
+            if (local) { const int kx = kx_lo + off; ok = ok && ky >= qy - 3 && ky <= qy + 3 && kx >= qx - 5 && kx <= qx + 5; }
             sc[j] = ok ? sc[j] * scale : -3.0e38f;
             tmax = fmaxf(tmax, sc[j]);
         }
@@ -262,7 +323,7 @@ __global__ __launch_bounds__(64 * MA_W) void svtr_attn_mfma_kernel(const bf16_t*
         for (int j = 0; j < 16; j += 2) {
             const float p0 = sc[j] > -1.0e38f ? expf(sc[j] - mn) : 0.f, p1 = sc[j + 1] > -1.0e38f ? expf(sc[j + 1] - mn) : 0.f;
             psum += p0 + p1;
-            pk[j >> 1] = pack_bf16x2(p0, p1);
+            pk[j >> 1] = NM::pack(p0, p1);
         }
         psum += __shfl_xor(psum, 32);
         l = l * corr + psum;
@@ -271,71 +332,95 @@ __global__ __launch_bounds__(64 * MA_W) void svtr_attn_mfma_kernel(const bf16_t*
         for (int j = 0; j < 16; ++j) o[j] *= corr;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            // keys 16*ks .. +15 of the tile: X = registers 8*ks .. +3 (packed pk[4ks], pk[4ks+1]), Y = registers 8*ks+4 .. +7
             const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * ks], pk[4 * ks + 2], false, false);
             const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 1], pk[4 * ks + 3], false, false);
-            union { uint32_t u[4]; bf16x8_t v; } pf;
+            union { uint32_t u[4]; typename NM::frag_t v; } pf;
             pf.u[0] = s0[0]; pf.u[1] = s1[0]; pf.u[2] = s0[1]; pf.u[3] = s1[1];
-            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sVt + (size_t)r * vp + k0 + ks * 16 + h * 8);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o, 0, 0, 0);
+            const typename NM::frag_t vf = *reinterpret_cast<const typename NM::frag_t*>(sVt + (size_t)r * vp + k0 + ks * 16 + h * 8);
+            o = NM::mfma(vf, pf.v, o);
         }
     }
-    if (q0 + r < T) {   // lane (query = r): register j is d = (j & 3) + 8 * (j >> 2) + 4 * h
+    if (qvalid) {   // lane (query = r): register j is d = (j & 3) + 8 * (j >> 2) + 4 * h
         const float inv = 1.0f / l;
-        bf16_t* dst = out + ((size_t)n * T + q0 + r) * C + hd * AT_HD;
+        uint16_t* dst = out + ((size_t)n * T + qraw) * C + hd * AT_HD;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 w;
-            w.x = pack_bf16x2(o[4 * g] * inv, o[4 * g + 1] * inv);
-            w.y = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            w.x = NM::pack(o[4 * g] * inv, o[4 * g + 1] * inv);
+            w.y = NM::pack(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
             *reinterpret_cast<uint2*>(dst + 8 * g + 4 * h) = w;
         }
     }
 }
 
-inline int grid_for(size_t total) {
-    size_t g = (total + 255) / 256;
-    return (int)(g > 256 * 32 ? 256 * 32 : (g ? g : 1));
+// y[n, x, c] = T(mean over the H rows of x[n, :, x, c])
+template <int DT>
+__global__ void svtr_rowmean_kernel(const uint16_t* x, uint16_t* y, int N, int H, int W, int C) {
+    const size_t total = (size_t)N * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t t = i / C;
+        const int xw = (int)(t % W), n = (int)(t / W);
+        float s = 0.f;
+        for (int rr = 0; rr < H; ++rr) s += Num<DT>::one(x[(((size_t)n * H + rr) * W + xw) * C + c]);
+        y[i] = Num<DT>::cvt(s / (float)H);
+    }
+}
+
+template <int DT, int NT, bool LN>
+hipError_t gemm_launch_t(const SvtrGemmParams& p, hipStream_t st) {
+    auto kern = svtr_gemm_kernel<DT, NT, LN>;
+    { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(kern), GCfg<NT>::LDS); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(kern, dim3((p.M + G_BM - 1) / G_BM, p.N / (32 * NT)), dim3(256), GCfg<NT>::LDS, st, p);
+    return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t svtr_add_pos_launch(const bf16_t* x, const bf16_t* pos, bf16_t* y, int N, int T, int C, hipStream_t st) {
-    const size_t total8 = (size_t)N * T * C / 8;
-    hipLaunchKernelGGL(svtr_add_pos_kernel, dim3(grid_for(total8)), dim3(256), 0, st, x, pos, y, total8, T * C / 8);
+hipError_t svtr_im2col_launch(const uint8_t* crops, const int* widths, uint16_t* out, int N, int dtype, hipStream_t st) {
+    const int g = grid_for((size_t)N * 2560);
+    if (dtype) hipLaunchKernelGGL(svtr_im2col_kernel<1>, dim3(g), dim3(256), 0, st, crops, widths, out, N);
+    else hipLaunchKernelGGL(svtr_im2col_kernel<0>, dim3(g), dim3(256), 0, st, crops, widths, out, N);
     return hipGetLastError();
 }
 
-hipError_t svtr_layernorm_launch(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int N, int Hin, int Hout, int W, int C, int row_step,
-                                 float eps, hipStream_t st) {
-    const long long tokens = (long long)N * Hout * W;
-    const dim3 grid((unsigned)((tokens + 3) / 4));
-    if (C == 64) hipLaunchKernelGGL(svtr_layernorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, N, Hin, Hout, W, row_step, eps);
-    else if (C == 128) hipLaunchKernelGGL(svtr_layernorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, N, Hin, Hout, W, row_step, eps);
-    else if (C == 256) hipLaunchKernelGGL(svtr_layernorm_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, N, Hin, Hout, W, row_step, eps);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
-}
-
-hipError_t svtr_rowmean_launch(const bf16_t* x, bf16_t* y, int N, int H, int W, int C, hipStream_t st) {
-    hipLaunchKernelGGL(svtr_rowmean_kernel, dim3(grid_for((size_t)N * W * C)), dim3(256), 0, st, x, y, N, H, W, C);
-    return hipGetLastError();
-}
-
-hipError_t svtr_attention_launch(const bf16_t* qkv, bf16_t* out, int N, int T, int heads, int gh, int gw, int local, hipStream_t st) {
-    if (gh * gw != T || N <= 0 || gw < 32) return hipErrorInvalidValue;
-    size_t lds = (size_t)T * AT_HD * (4 + 2);   // K fp32 + V bf16; the merge buffer aliases K
-    if (lds < (size_t)AT_PARTS * 64 * AT_RED * sizeof(float)) lds = (size_t)AT_PARTS * 64 * AT_RED * sizeof(float);
-    if (lds > 150 * 1024) return hipErrorInvalidValue;
-    { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(svtr_attn_kernel), 150 * 1024); if (e != hipSuccess) return e; }
-    static const bool valu = getenv("LUMINA_SVTR_ATTN_VALU") != nullptr;   // A/B switch: the fp32 VALU kernel
-    if (!valu && T % 32 == 0) {
-        const int Tpad = (T + 31) & ~31;
-        const size_t lds2 = (size_t)Tpad * MA_KP * 2 + (size_t)32 * (T + 8) * 2;
-        { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(svtr_attn_mfma_kernel), 150 * 1024); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(svtr_attn_mfma_kernel, dim3((T + 32 * MA_W - 1) / (32 * MA_W), heads, N), dim3(64 * MA_W), lds2, st, qkv, out, T, heads, gh, gw, local);
-        return hipGetLastError();
+hipError_t svtr_gemm_launch(const SvtrGemmParams& p, int dtype, hipStream_t st) {
+    if (p.M <= 0 || p.K <= 0 || p.K % G_BK != 0 || p.N % 32 != 0 || (p.taps != 1 && p.taps != 9) || p.K != p.taps * p.Cin || p.Cin % G_BK != 0 ||
+        p.zeros == nullptr || p.Tout <= 0 || p.Wout <= 0)
+        return hipErrorInvalidValue;
+    if ((long long)p.M * p.N >= (1ll << 40)) return hipErrorInvalidValue;
+    const bool ln = p.gamma != nullptr;
+    // tile width: a LayerNorm epilogue needs the whole token (N = 64 .. 384 channels) in one work-group; other layers use 128-channel tiles
+    int nt = ln ? p.N / 32 : ((p.N % 128 == 0) ? 4 : (p.N % 192 == 0 ? 6 : (p.N % 64 == 0 ? 2 : (p.N == 32 ? 1 : 0))));
+#define GL(DT_, NT_, LN_) return gemm_launch_t<DT_, NT_, LN_>(p, st)
+#define GD(NT_, LN_) { if (dtype) GL(1, NT_, LN_); else GL(0, NT_, LN_); }
+    if (ln) {
+        switch (nt) { case 2: GD(2, true) case 4: GD(4, true) case 8: GD(8, true) case 12: GD(12, true) default: return hipErrorInvalidValue; }
     }
-    hipLaunchKernelGGL(svtr_attn_kernel, dim3((T + AT_Q - 1) / AT_Q, heads, N), dim3(64 * AT_PARTS), lds, st, qkv, out, T, heads, gh, gw, local);
+    switch (nt) { case 1: GD(1, false) case 2: GD(2, false) case 4: GD(4, false) case 6: GD(6, false) default: return hipErrorInvalidValue; }
+#undef GD
+#undef GL
+}
+
+hipError_t svtr_rowmean_launch(const uint16_t* x, uint16_t* y, int N, int H, int W, int C, int dtype, hipStream_t st) {
+    if (dtype) hipLaunchKernelGGL(svtr_rowmean_kernel<1>, dim3(grid_for((size_t)N * W * C)), dim3(256), 0, st, x, y, N, H, W, C);
+    else hipLaunchKernelGGL(svtr_rowmean_kernel<0>, dim3(grid_for((size_t)N * W * C)), dim3(256), 0, st, x, y, N, H, W, C);
+    return hipGetLastError();
+}
+
+hipError_t svtr_attention_launch(const uint16_t* qkv, uint16_t* out, int N, int T, int heads, int gh, int gw, int local, int dtype, hipStream_t st) {
+    if (gh * gw != T || N <= 0 || gw < 32 || gw % 8 != 0 || (local && gh % 4 != 0)) return hipErrorInvalidValue;
+    const int Tpad = ((T + 31) & ~31) + 32;
+    const size_t lds = (size_t)Tpad * MA_KP * 2 + (size_t)32 * (Tpad + 8) * 2;
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    const int tiles = local ? (gh / 4) * (gw / 8) : (T + 31) / 32;
+    const dim3 grid((tiles + MA_W - 1) / MA_W, heads, N);
+    if (dtype) {
+        { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(svtr_attn_kernel<1>), 150 * 1024); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(svtr_attn_kernel<1>, grid, dim3(64 * MA_W), lds, st, qkv, out, T, heads, gh, gw, local);
+    } else {
+        { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(svtr_attn_kernel<0>), 150 * 1024); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(svtr_attn_kernel<0>, grid, dim3(64 * MA_W), lds, st, qkv, out, T, heads, gh, gw, local);
+    }
     return hipGetLastError();
 }

@@ -372,29 +372,47 @@ def make_rec_weights(seed: int = 4321, num_classes: int = 6625, scale: float = 0
 # (Du et al., "SVTR: Scene Text Recognition with a Single Visual Model", tiny configuration, post-norm blocks) on the 32 x 320
 # crops of this pipeline: 8 x 80 tokens -> 4 x 80 -> 2 x 80 -> 80 time steps.  "Parity unpinned".
 # --------------------------------------------------------------------------------------
-SVTR_DIMS, SVTR_DEPTHS, SVTR_HEADS = (64, 128, 256), (3, 6, 3), (2, 4, 8)
-SVTR_LOCAL_BLOCKS = 6            # the first 6 of the 12 blocks mix locally (window 7 x 11 tokens), the rest globally
+SVTR_VARIANTS = {
+    # dims, depths, heads (head width 32), local mixing blocks (the first ones), channels of the sequence handed to the CTC head
+    "tiny": dict(dims=(64, 128, 256), depths=(3, 6, 3), heads=(2, 4, 8), local_blocks=6, out=192),
+    "base": dict(dims=(128, 256, 384), depths=(3, 6, 9), heads=(4, 8, 12), local_blocks=8, out=192),   # BASELINE configs[4]
+}
+SVTR_DIMS, SVTR_DEPTHS, SVTR_HEADS = SVTR_VARIANTS["tiny"]["dims"], SVTR_VARIANTS["tiny"]["depths"], SVTR_VARIANTS["tiny"]["heads"]
+SVTR_LOCAL_BLOCKS = 6            # (tiny) the first 6 of the 12 blocks mix locally (window 7 x 11 tokens), the rest globally
 SVTR_WINDOW = (7, 11)
 SVTR_OUT = 192                   # channels of the sequence handed to the CTC head
 SVTR_LN_EPS = 1e-6
+SVTR_DTYPES = {"bf16": 0, "f16": 1}
 
 
-def svtr_block_table() -> List[dict]:
+def svtr_config(weights=None, variant: str = "tiny") -> dict:
+    """The variant a weight dict / blob describes (its `svtr.config` tensor), or the named one."""
+    if weights is not None and "svtr.config" in weights:
+        c = [int(v) for v in np.asarray(weights["svtr.config"]).tolist()]
+        return dict(dims=tuple(c[0:3]), depths=tuple(c[3:6]), heads=tuple(c[6:9]), local_blocks=c[9], out=c[10], dtype="f16" if c[11] else "bf16")
+    return dict(SVTR_VARIANTS[variant], dtype="bf16")
+
+
+def svtr_block_table(cfg=None) -> List[dict]:
     """One entry per mixing block: stage, dim, heads, token grid (h, w), local / global."""
+    cfg = cfg or svtr_config()
     rows, idx, h = [], 0, REC_H // 4
-    for s, (dim, depth, heads) in enumerate(zip(SVTR_DIMS, SVTR_DEPTHS, SVTR_HEADS)):
+    for s, (dim, depth, heads) in enumerate(zip(cfg["dims"], cfg["depths"], cfg["heads"])):
         for _ in range(depth):
-            rows.append(dict(idx=idx, stage=s, dim=dim, heads=heads, h=h, w=REC_W // 4, local=idx < SVTR_LOCAL_BLOCKS))
+            rows.append(dict(idx=idx, stage=s, dim=dim, heads=heads, h=h, w=REC_W // 4, local=idx < cfg["local_blocks"]))
             idx += 1
         h //= 2
     return rows
 
 
-def make_svtr_weights(seed: int = 2468, num_classes: int = 6625) -> Dict[str, np.ndarray]:
+def make_svtr_weights(seed: int = 2468, num_classes: int = 6625, variant: str = "tiny", dtype: str = "bf16") -> Dict[str, np.ndarray]:
     """Seeded weights in the LOCW naming: conv / linear weights OHWI `[out, kh, kw, in]` (.w, bf16), biases and LayerNorm
-    gamma / beta fp32 (.b / .g)."""
+    gamma / beta fp32 (.b / .g); `svtr.config` (f32 [12]) carries the variant and the storage / MFMA type the engine shall use."""
     rng = np.random.default_rng(seed)
+    cfg = SVTR_VARIANTS[variant]
+    dims = cfg["dims"]
     w: Dict[str, np.ndarray] = {}
+    w["svtr.config"] = np.array(list(dims) + list(cfg["depths"]) + list(cfg["heads"]) + [cfg["local_blocks"], cfg["out"], SVTR_DTYPES[dtype]], np.float32)
 
     def conv(name, cout, k, cin, gain=1.0):
         w[name + ".w"] = _he(rng, cout, k, cin, gain)
@@ -404,10 +422,10 @@ def make_svtr_weights(seed: int = 2468, num_classes: int = 6625) -> Dict[str, np
         w[name + ".g"] = (1.0 + 0.1 * rng.standard_normal(c)).astype(np.float32)
         w[name + ".b"] = (0.05 * rng.standard_normal(c)).astype(np.float32)
 
-    conv("svtr.pe1", SVTR_DIMS[0] // 2, 3, 3, gain=1.3)
-    conv("svtr.pe2", SVTR_DIMS[0], 3, SVTR_DIMS[0] // 2, gain=1.3)
-    w["svtr.pos.w"] = bf16_round((0.5 * rng.standard_normal(((REC_H // 4) * (REC_W // 4), SVTR_DIMS[0]))).astype(np.float32))
-    for b in svtr_block_table():
+    conv("svtr.pe1", dims[0] // 2, 3, 3, gain=1.3)
+    conv("svtr.pe2", dims[0], 3, dims[0] // 2, gain=1.3)
+    w["svtr.pos.w"] = bf16_round((0.5 * rng.standard_normal(((REC_H // 4) * (REC_W // 4), dims[0]))).astype(np.float32))
+    for b in svtr_block_table(dict(cfg)):
         p, c = f"svtr.b{b['idx']}", b["dim"]
         conv(p + ".qkv", 3 * c, 1, c, gain=0.8)
         conv(p + ".proj", c, 1, c, gain=0.15)   # small residual branches: with untrained weights larger ones wash the token identity out
@@ -416,10 +434,10 @@ def make_svtr_weights(seed: int = 2468, num_classes: int = 6625) -> Dict[str, np
         conv(p + ".fc2", c, 1, 4 * c, gain=0.15)
         ln(p + ".ln2", c)
     for s in range(2):
-        conv(f"svtr.sub{s}", SVTR_DIMS[s + 1], 3, SVTR_DIMS[s], gain=1.0)
-        ln(f"svtr.sub{s}.ln", SVTR_DIMS[s + 1])
-    conv("svtr.last", SVTR_OUT, 1, SVTR_DIMS[2], gain=1.4)
-    w["svtr.ctc.fc.w"] = bf16_round(rng.standard_normal((num_classes, SVTR_OUT), dtype=np.float32) * np.float32(12.0 / np.sqrt(SVTR_OUT)))
+        conv(f"svtr.sub{s}", dims[s + 1], 3, dims[s], gain=1.0)
+        ln(f"svtr.sub{s}.ln", dims[s + 1])
+    conv("svtr.last", cfg["out"], 1, dims[2], gain=1.4)
+    w["svtr.ctc.fc.w"] = bf16_round(rng.standard_normal((num_classes, cfg["out"]), dtype=np.float32) * np.float32(12.0 / np.sqrt(cfg["out"])))
     w["svtr.ctc.fc.b"] = (rng.standard_normal(num_classes, dtype=np.float32) * np.float32(0.1)).astype(np.float32)
     return w
 

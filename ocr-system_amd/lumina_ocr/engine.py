@@ -70,6 +70,7 @@ def load_library() -> ctypes.CDLL:
         "lumina_ocr_load_svtr_weights": (i32, [vp, vp, sz]),
         "lumina_ocr_svtr_forward": (i32, [vp, vp, vp, i32, vp, vp, vp]),
         "lumina_ocr_svtr_num_classes": (i32, [vp]),
+        "lumina_ocr_svtr_dtype": (i32, [vp]),
         "lumina_ocr_deskew": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "lumina_ocr_deskew_warp": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     }
@@ -93,7 +94,7 @@ EXPORTED_SYMBOLS = [
     "lumina_ocr_det_forward", "lumina_ocr_det_postprocess", "lumina_ocr_rec_crop", "lumina_ocr_rec_forward",
     "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing", "lumina_ocr_conv_timing_detail",
     "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients",
-    "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward", "lumina_ocr_svtr_num_classes", "lumina_ocr_deskew", "lumina_ocr_deskew_warp",
+    "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward", "lumina_ocr_svtr_num_classes", "lumina_ocr_svtr_dtype", "lumina_ocr_deskew", "lumina_ocr_deskew_warp",
 ]
 
 
@@ -185,13 +186,16 @@ class Engine:
         self.num_classes = self.lib.lumina_ocr_num_classes(self._h)
         self.rec_loaded = True
 
-    def load_svtr(self, weights):
-        """SVTR-Tiny recogniser weights (arch.make_svtr_weights or a LOCW blob with the svtr.* tensors)."""
+    def load_svtr(self, weights, f16=None):
+        """SVTR recogniser weights (arch.make_svtr_weights or a LOCW blob with the svtr.* tensors): Tiny or Base, bf16 or fp16 as the
+        blob's svtr.config says; f16 = True / False overrides the storage / MFMA type."""
+        self.set_option("svtr_f16", -1 if f16 is None else int(bool(f16)))
         blob = weights if isinstance(weights, (bytes, bytearray)) else arch.write_blob(weights)
         buf = ctypes.create_string_buffer(bytes(blob), len(blob))
         self._chk(self.lib.lumina_ocr_load_svtr_weights(self._h, ctypes.cast(buf, ctypes.c_void_p), len(blob)))
         self.svtr_loaded = True
         self.svtr_num_classes = self.lib.lumina_ocr_svtr_num_classes(self._h)
+        self.svtr_dtype = "f16" if self.lib.lumina_ocr_svtr_dtype(self._h) else "bf16"
 
     # -- hot path -------------------------------------------------------------------------
     def normalize(self, img, hp: int, wp: int, scale, shift, nchw: bool = False):
@@ -283,13 +287,15 @@ class Engine:
                                              _ptr(res), _ptr(y), self._stream()))
         return y
 
-    def read_tap(self, name: str) -> np.ndarray:
+    def read_tap(self, name: str, dtype: str = "bf16") -> np.ndarray:
+        """Intermediate tensor of the last forward as float32 (dtype: the storage type of that tensor — "f16" for an SVTR fp16 model)."""
         dims = (ctypes.c_int * 4)()
         self._chk(self.lib.lumina_ocr_read_tap(self._h, name.encode(), None, 0, dims))
         n = int(np.prod(list(dims)))
         buf = np.empty(n, np.uint16)
         self._chk(self.lib.lumina_ocr_read_tap(self._h, name.encode(), buf.ctypes.data, n, dims))
-        return arch.bf16_bits_to_f32(buf).reshape(tuple(dims))
+        vals = buf.view(np.float16).astype(np.float32) if dtype == "f16" else arch.bf16_bits_to_f32(buf)
+        return vals.reshape(tuple(dims))
 
     def conv_timing(self) -> Tuple[float, float, int]:
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()

@@ -29,7 +29,12 @@ from lumina_ocr import arch  # noqa: E402  (layer tables only)
 
 
 def _rb(x: torch.Tensor, mode: str) -> torch.Tensor:
-    return x.to(torch.bfloat16).to(torch.float32) if mode == "bf16" else x
+    """One rounding of a stored tensor: bf16 (the engine's default storage type), f16 (SVTR fp16 mode) or none (mode "fp32")."""
+    if mode == "bf16":
+        return x.to(torch.bfloat16).to(torch.float32)
+    if mode == "f16":
+        return x.to(torch.float16).to(torch.float32)
+    return x
 
 
 def _act(x: torch.Tensor, act: str) -> torch.Tensor:
@@ -259,18 +264,19 @@ def _svtr_mask(h, w):
 
 
 def svtr_backbone(wd, x, mode="bf16", taps=None):
-    """x [N,3,32,320] normalised -> sequence [N,80,192]."""
+    """x [N,3,32,320] normalised -> sequence [N,80,192].  Variant (Tiny / Base) = wd["svtr.config"] (arch.svtr_config)."""
     def tap(name, t):
         if taps is not None:
             taps[name] = t.contiguous().numpy()
 
+    cfg = arch.svtr_config(wd)
     x = conv_bn_act(x, wd, "svtr.pe1", 2, "gelu", mode=mode)
-    x = conv_bn_act(x, wd, "svtr.pe2", 2, "gelu", mode=mode)                 # [N,64,8,80]
+    x = conv_bn_act(x, wd, "svtr.pe2", 2, "gelu", mode=mode)                 # [N,D0,8,80]
     n, c, h, w = x.shape
     t = x.permute(0, 2, 3, 1).reshape(n, h * w, c)
-    t = _rb(t + torch.from_numpy(wd["svtr.pos.w"]), mode); tap("svtr.embed", t)
+    t = _rb(t + _rb(torch.from_numpy(wd["svtr.pos.w"]), mode), mode); tap("svtr.embed", t)
     stage = 0
-    for b in arch.svtr_block_table():
+    for b in arch.svtr_block_table(cfg):
         if b["stage"] != stage:                                               # height merging: conv 3x3 stride (2,1) + LayerNorm
             img = t.reshape(n, h, w, c).permute(0, 3, 1, 2)
             img = conv_bn_act(img, wd, f"svtr.sub{stage}", (2, 1), "none", mode=mode)
@@ -287,13 +293,15 @@ def svtr_backbone(wd, x, mode="bf16", taps=None):
         t = _layernorm(_linear(att, wd, p + ".proj", residual=t, mode=mode), wd, p + ".ln1", mode)
         m = _linear(t, wd, p + ".fc1", act="gelu", mode=mode)
         t = _layernorm(_linear(m, wd, p + ".fc2", residual=t, mode=mode), wd, p + ".ln2", mode); tap(p, t)
-    pooled = _rb(t.reshape(n, h, w, c).mean(dim=1), mode)                     # [N,80,256]: mean over the 2 remaining rows
+    pooled = _rb(t.reshape(n, h, w, c).mean(dim=1), mode)                     # [N,80,C2]: mean over the 2 remaining rows
     seq = _linear(pooled, wd, "svtr.last", act="hswish", mode=mode); tap("svtr.seq", seq)
     return seq
 
 
-def svtr_forward(wd, crops_u8: np.ndarray, mode="bf16", taps=None, widths=None):
-    """crops [N,32,320,3] u8 -> (argmax idx [N,80], max prob [N,80] f32, logits, seq)."""
+def svtr_forward(wd, crops_u8: np.ndarray, mode=None, taps=None, widths=None):
+    """crops [N,32,320,3] u8 -> (argmax idx [N,80], max prob [N,80] f32, logits, seq).  mode None: the storage type the weights'
+    svtr.config names ("bf16" / "f16"; weights are bf16-exact values, which fp16 represents exactly)."""
+    mode = mode or arch.svtr_config(wd)["dtype"]
     with torch.no_grad():
         x = rec_normalize(crops_u8, mode)
         if widths is not None:

@@ -97,30 +97,44 @@ def test_config4_end_to_end_a4_pages_and_detector_recall(engine, det_weights, re
     assert hit >= 0.75 * len(gt), (hit, len(gt), len(dets[0].quads))
 
 
-def test_config5_svtr_recogniser_batch512_and_devanagari_charset(engine):
-    """BASELINE configs[4] (SVTR recogniser, Hindi dictionary): SVTR-Tiny on 512 crops with a Devanagari class list — batch and
-    sub-batch invariance at size, the oracle on a bounded sample, CTC decode exact on the same ids.  No Hindi dictionary, image or
-    weights ship offline: the class list is the build's own (arch.devanagari_charset), weights are seeded."""
+def test_config5_svtr_base_fp16_batch512_with_a_dictionary_file(engine, tmp_path):
+    """BASELINE configs[4]: SVTR-BASE, fp16 MFMA, Hindi dictionary, batch 512 — batch and sub-batch invariance at size, the oracle
+    (fp16 storage) on a bounded sample incl. taps of the last block of every stage, CTC decode exact on the same ids, strings through
+    a dictionary FILE (PP-OCR key-file format) loaded the way the provider loads LUMINA_OCR_REC_DICT.  No Hindi dictionary, image or
+    weights ship offline: the file is written from the build's own list (arch.devanagari_charset), weights are seeded."""
     from oracle import nets
-    cs = arch.devanagari_charset()
-    weights = arch.make_svtr_weights(num_classes=len(cs))
+    f = tmp_path / "devanagari_dict.txt"
+    arch.save_charset(f, arch.devanagari_charset())
+    cs = arch.load_charset(f)
+    assert cs == arch.devanagari_charset()
+    weights = arch.make_svtr_weights(num_classes=len(cs), variant="base", dtype="f16")
     rng = np.random.default_rng(55)
     base = np.stack([synth.synth_crop(rng)[0] for _ in range(64)])
     crops = torch.from_numpy(np.concatenate([base] * 8)).cuda()
     engine.load_svtr(weights)
-    engine.set_option("rec_sub_batch", 300)                                # SVTR sub-batches of 150: 150 + 150 + 150 + 62
+    assert engine.svtr_dtype == "f16" and engine.svtr_num_classes == len(cs)
+    engine.set_option("rec_sub_batch", 600)                                # SVTR-Base sub-batches of 150: 150 + 150 + 150 + 62
     idx, prob = engine.svtr_forward(crops)
     engine.set_option("rec_sub_batch", 4096)
+    engine.set_option("keep_taps", 1)
     idx2, prob2 = engine.svtr_forward(crops)
     torch.cuda.synchronize()
+    engine.set_option("keep_taps", 0)
     assert torch.equal(idx, idx2) and torch.equal(prob, prob2)
     for r in range(1, 8):
         assert torch.equal(idx[:64], idx[64 * r:64 * r + 64])
     assert int(idx.max()) < len(cs)
-    ridx, rprob, _, _ = nets.svtr_forward(weights, base[:6])
-    assert float((idx[:6].cpu().numpy() == ridx).mean()) > 0.9
+    taps = {}
+    ridx, rprob, _, _ = nets.svtr_forward(weights, base[:4], None, taps)
+    for name in ("svtr.b2", "svtr.b8", "svtr.b17", "svtr.seq"):           # last block of each stage + the sequence (first 4 crops)
+        got = engine.read_tap(name, "f16")
+        got = got.reshape((got.shape[0], -1, got.shape[-1]))[:4]
+        st = close_stats(got, taps[name])
+        assert st["within4"] > 0.95 and st["mean_abs"] < 0.02 * max(st["ref_mean_abs"], 1e-3), (name, st)
+    assert float((idx[:4].cpu().numpy() == ridx).mean()) > 0.97
     text, length, score = engine.ctc_decode(idx, prob)
     ref = nets.ctc_greedy(idx[:6].cpu().numpy(), prob[:6].cpu().numpy(), cs)
+    dec = arch.TextDecoder(cs)
+    got = dec.decode(text[:6].cpu().numpy(), length[:6].cpu().numpy())
     for i in range(6):
-        got = "".join(cs[k] for k in text[i, : int(length[i])].cpu().tolist())
-        assert got == ref[i][0] and np.float32(score[i].item()) == np.float32(ref[i][1])
+        assert got[i] == ref[i][0] and np.float32(score[i].item()) == np.float32(ref[i][1])
