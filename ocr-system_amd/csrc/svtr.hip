@@ -84,17 +84,21 @@ __global__ __launch_bounds__(256) void svtr_im2col_kernel(const uint8_t* crops, 
 }
 
 // ------------------------------------------------------------------------------------------------ GEMM with gather + fused epilogue
-constexpr int G_BM = 128, G_BK = 32;
-template <int NT> struct GCfg {
-    static constexpr int BN = 32 * NT;
-    static constexpr int X_BYTES = G_BM * G_BK * 2, W_BYTES = BN * G_BK * 2, BUF = X_BYTES + W_BYTES;
+constexpr int G_BM = 128;
+template <int NT, int BK> struct GCfg {
+    static constexpr int BN = 32 * NT, SL = BK / 8;                           // 16-byte k-slices per row and stage
+    static constexpr int X_BYTES = G_BM * BK * 2, W_BYTES = BN * BK * 2, BUF = X_BYTES + W_BYTES;
     static constexpr int LDS = 2 * BUF;
-    static constexpr int XIT = (G_BM * 4) / 256, WIT = (BN * 4 + 255) / 256;   // 16-byte pieces per thread and stage
+    static constexpr int XIT = (G_BM * SL) / 256, WIT = (BN * SL + 255) / 256;   // 16-byte pieces per thread and stage
+    // slot of k-slice s in row q: s ^ swz(q); 16 consecutive rows must cover the 16 slots of the 256-byte bank row exactly once
+    static __host__ __device__ constexpr int swz(int q) { return BK == 32 ? ((q >> 2) & 3) : ((q >> 1) & 7); }
 };
 
-template <int DT, int NT, bool LN>
-__global__ __launch_bounds__(256, (NT <= 6 ? 2 : 1)) void svtr_gemm_kernel(const SvtrGemmParams p) {
-    using C = GCfg<NT>;
+// BK = 64 halves the barriers per MFMA (layers whose input channels come in multiples of 64); BK = 32 serves the rest
+template <int DT, int NT, bool LN, int BK>
+__global__ __launch_bounds__(256, (GCfg<NT, BK>::LDS <= 80 * 1024 && NT <= 6 ? 2 : 1)) void svtr_gemm_kernel(const SvtrGemmParams p) {
+    using C = GCfg<NT, BK>;
+    constexpr int G_BK = BK, SL = C::SL;
     using NM = Num<DT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256, (NT <= 6 ? 2 : 1)) void svtr_gemm_kernel(const
     int x_n[C::XIT], x_oy[C::XIT], x_ox[C::XIT];
 #pragma unroll
     for (int it = 0; it < C::XIT; ++it) {
-        const int i = tid + 256 * it, q = i >> 2, s = (i & 3) ^ ((q >> 2) & 3);
+        const int i = tid + 256 * it, q = i / SL, s = (i % SL) ^ C::swz(q);
         x_row[it] = q; x_sl[it] = s;
         int m = m0 + q;
         if (m >= p.M) m = p.M - 1;
@@ -134,24 +138,24 @@ __global__ __launch_bounds__(256, (NT <= 6 ? 2 : 1)) void svtr_gemm_kernel(const
 #pragma unroll
         for (int it = 0; it < C::WIT; ++it) {
             const int i = tid + 256 * it;
-            if (C::BN * 4 % 256 == 0 || i < C::BN * 4) {
-                const int q = i >> 2, s = (i & 3) ^ ((q >> 2) & 3);
+            if (C::BN * SL % 256 == 0 || i < C::BN * SL) {
+                const int q = i / SL, s = (i % SL) ^ C::swz(q);
                 const uint16_t* src = wt + (size_t)q * p.K + kb * G_BK + s * 8;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + C::X_BYTES + (i - lane) * 16), 16, 0, 0);
             }
         }
     };
-    static_assert((C::BN * 4) % 64 == 0, "weight pieces split on wave boundaries");
+    static_assert((C::BN * SL) % 64 == 0, "weight pieces split on wave boundaries");
 
     f32x16_t acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[nt][j] = 0.f;
-    // fragment read offsets: row q, k-slice (2 ks + h) -> slot (2 ks + h) ^ ((q >> 2) & 3)
+    // fragment read offsets: row q, k-slice (2 ks + h) -> slot (2 ks + h) ^ swz(q)
     const int xq = wave * 32 + r;
-    const int xoff = xq * 64, xsw = (xq >> 2) & 3;
-    const int wsw = (r >> 2) & 3;   // weight row q = nt * 32 + r: (q >> 2) & 3 == (r >> 2) & 3
+    const int xoff = xq * (BK * 2), xsw = C::swz(xq);
+    const int wsw = C::swz(r);   // weight row q = nt * 32 + r: swz(q) == swz(r)
 
     stage(0, 0);
     for (int kb = 0; kb < nk; ++kb) {
@@ -160,11 +164,11 @@ __global__ __launch_bounds__(256, (NT <= 6 ? 2 : 1)) void svtr_gemm_kernel(const
         if (kb + 1 < nk) stage(kb + 1, (kb + 1) & 1);
         const unsigned char* buf = smem + (kb & 1) * C::BUF;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             const typename NM::frag_t xb = *reinterpret_cast<const typename NM::frag_t*>(buf + xoff + (((2 * ks + h) ^ xsw) << 4));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const typename NM::frag_t wa = *reinterpret_cast<const typename NM::frag_t*>(buf + C::X_BYTES + (nt * 32 + r) * 64 + (((2 * ks + h) ^ wsw) << 4));
+                const typename NM::frag_t wa = *reinterpret_cast<const typename NM::frag_t*>(buf + C::X_BYTES + (nt * 32 + r) * (BK * 2) + (((2 * ks + h) ^ wsw) << 4));
                 acc[nt] = NM::mfma(wa, xb, acc[nt]);
             }
         }
@@ -367,12 +371,20 @@ __global__ void svtr_rowmean_kernel(const uint16_t* x, uint16_t* y, int N, int H
     }
 }
 
+template <int DT, int NT, bool LN, int BK>
+hipError_t gemm_launch_bk(const SvtrGemmParams& p, hipStream_t st) {
+    auto kern = svtr_gemm_kernel<DT, NT, LN, BK>;
+    constexpr int lds = GCfg<NT, BK>::LDS;
+    { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(kern, dim3((p.M + G_BM - 1) / G_BM, p.N / (32 * NT)), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
 template <int DT, int NT, bool LN>
 hipError_t gemm_launch_t(const SvtrGemmParams& p, hipStream_t st) {
-    auto kern = svtr_gemm_kernel<DT, NT, LN>;
-    { hipError_t e = locr_dyn_lds(reinterpret_cast<const void*>(kern), GCfg<NT>::LDS); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(kern, dim3((p.M + G_BM - 1) / G_BM, p.N / (32 * NT)), dim3(256), GCfg<NT>::LDS, st, p);
-    return hipGetLastError();
+    // (measured: a 64-deep K step or four work-groups per CU change nothing for the 128-channel tiles: these short-K products are
+    // bound by the bytes of their operands and results, ~100 FLOP per byte, not by barriers)
+    if constexpr (NT >= 6) { if (p.Cin % 64 == 0) return gemm_launch_bk<DT, NT, LN, 64>(p, st); }
+    return gemm_launch_bk<DT, NT, LN, 32>(p, st);
 }
 
 }  // namespace
@@ -385,7 +397,7 @@ hipError_t svtr_im2col_launch(const uint8_t* crops, const int* widths, uint16_t*
 }
 
 hipError_t svtr_gemm_launch(const SvtrGemmParams& p, int dtype, hipStream_t st) {
-    if (p.M <= 0 || p.K <= 0 || p.K % G_BK != 0 || p.N % 32 != 0 || (p.taps != 1 && p.taps != 9) || p.K != p.taps * p.Cin || p.Cin % G_BK != 0 ||
+    if (p.M <= 0 || p.K <= 0 || p.K % 32 != 0 || p.N % 32 != 0 || (p.taps != 1 && p.taps != 9) || p.K != p.taps * p.Cin || p.Cin % 32 != 0 ||
         p.zeros == nullptr || p.Tout <= 0 || p.Wout <= 0)
         return hipErrorInvalidValue;
     if ((long long)p.M * p.N >= (1ll << 40)) return hipErrorInvalidValue;
