@@ -125,7 +125,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pages", type=int, default=PAGES_PER_RANK, help="pages per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--det-sub-batch", type=int, default=16)
+    ap.add_argument("--det-sub-batch", type=int, default=64, help="pages per detector launch group (64: the whole step; +2 %% over 16)")
+    ap.add_argument("--deskew", action="store_true", help="also run the reference's default-on de-skew step (OpenCV there; off here: see config.deskew)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal, only with --dry-engine")
     ap.add_argument("--dry-engine", action="store_true", help="no GPU, fake recogniser outputs: rehearses launcher + gather on CPU")
     args = ap.parse_args()
@@ -180,7 +181,7 @@ def main():
         """k steps through run_many: step i's host-side string decode (multi-GPU: its result gather, on a side stream) overlaps
         the device work of step i+1; every step's work, including the last decode / gather, is finished when this returns."""
         dets = None
-        for d, _ in pipe.run_many(pages for _ in range(k)):
+        for d, _ in (pipe.run_many((pages for _ in range(k)), deskew=args.deskew) if not dry else pipe.run_many(pages for _ in range(k))):
             dets = d
         return dets
 
@@ -231,7 +232,10 @@ def main():
                        "parallelism": "pages sharded dp%d, 1 all-gather/step" % world,
                        "ranks": ranks_seen, "collective_backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if distributed else None,
                        "input": "pages pre-decoded (uint8 RGB) and resident in HBM when the timed region starts",
-                       "outside_timed_region": "image decode, host->device copy, JPEG hand-off of the processed page (3.7 ms per 64 pages on the device)"},
+                       "outside_timed_region": "image decode, host->device copy, JPEG hand-off of the processed page (3.7 ms per 64 pages on the device)",
+                       "det_sub_batch": args.det_sub_batch,
+                       "deskew": ("on" if args.deskew else "off: not part of det+rec; the reference's deskew needs OpenCV and is a no-op without it (image_preprocessing.py:383-385); "
+                                  "on the device it costs ~12 ms per 64 pages (DESIGN.md), run with --deskew to include it")},
             "roofline": roofline,
         }
         if dry:

@@ -78,9 +78,12 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
         return t;
     };
 
-    // halo pieces of this thread (the same for every tile) and their global offsets for the tile being requested
+    // multi-source input: chunk c comes from source c / cps, stored at 1 / 2^shift of the resolution with Cin / n_src channels
+    const int nsrc = p.n_src > 1 ? p.n_src : 1, cps = nchunks / nsrc;
+    // halo pieces of this thread (the same for every tile) and their global offsets for the tile / source being requested
     int a_goff[R_AIT];
-    auto describe = [&](const RingTile& t) {
+    auto describe = [&](const RingTile& t, int src) {
+        const int sh = nsrc > 1 ? p.xs_shift[src] : 0, cin_s = nsrc > 1 ? 16 * cps : p.Cin, ws = p.W >> sh;
 #pragma unroll
         for (int it = 0; it < R_AIT; ++it) {
             const int i = tid + 256 * it, pi = i >> 1, c = i & 1;
@@ -88,14 +91,17 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
             const int ly = t.oyb - 1 + hy, lx = t.oxb - 1 + hx;
             const bool inb = i < R_A_ITEMS && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
             const int cs = c ^ ((hx >> 3) & 1);   // LDS slot c of this pixel holds slice cs (bank swizzle, see the fragment reads)
-            a_goff[it] = inb ? (ly * sy + lx * sx) * (p.x_blk ? 16 : p.Cin) + cs * 8 : -1;
+            const int iy = TR ? lx : ly, ix = TR ? ly : lx;   // image row / column of the halo pixel
+            const int pix = nsrc > 1 ? (iy >> sh) * ws + (ix >> sh) : ly * sy + lx * sx;   // nearest-upsampled read of a low-resolution source
+            a_goff[it] = inb ? pix * (p.x_blk ? 16 : cin_s) + cs * 8 : -1;
             if (PROF && (p.dbg_skip & 8)) a_goff[it] = i * 8;   // timing experiment: a perfectly coalesced halo (wrong values)
         }
     };
     const bf16_t* ximg;
     const bf16_t* wbase;
-    auto rebase = [&](const RingTile& t) {
-        ximg = p.x + (size_t)t.n_img * p.H * p.W * p.Cin;
+    auto rebase = [&](const RingTile& t, int src) {
+        if (nsrc > 1) { const int sh = p.xs_shift[src]; ximg = p.xs[src] + (size_t)t.n_img * (p.H >> sh) * (p.W >> sh) * (16 * cps); }
+        else ximg = p.x + (size_t)t.n_img * p.H * p.W * p.Cin;
         wbase = p.wpk + (size_t)t.ntile * nchunks * (R_W_ITEMS * 8);
     };
 
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
     for (int i = tid; i < p.Cout; i += 256) reinterpret_cast<float*>(smem + 2 * R_BUF)[i] = p.bias[i];
     cur = decode(lid);
     RingTile nxt = cur;
-    describe(cur); rebase(cur);
+    describe(cur, 0); rebase(cur, 0);
     int boff = 0;
     const bf16_t* xa_n = ximg;    // source of the ring slot being requested: (tile, chunk) after the one being computed
     const bf16_t* ws_n = wbase;
@@ -344,12 +350,19 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
             __syncthreads();
             RING_T(t_bar)
             if (chunk + 1 < nchunks) {
-                xa_n += chunk_adv; ws_n += R_W_ITEMS * 8;
+                if (nsrc > 1 && (chunk + 1) % cps == 0) {   // the next chunk is the first of another source tensor
+                    describe(cur, (chunk + 1) / cps); rebase(cur, (chunk + 1) / cps);
+                    xa_n = ximg;
+                } else xa_n += chunk_adv;
+                ws_n += R_W_ITEMS * 8;
             } else if (next_lid < lid_end) {   // the ring runs on into the next tile
                 nxt = decode(next_lid);
-                describe(nxt); rebase(nxt);
+                describe(nxt, 0); rebase(nxt, 0);
                 xa_n = ximg; ws_n = wbase;
-            }                                  // (no next tile: the last chunk is requested once more, into the free slot)
+            } else if (nsrc > 1) {             // no next tile: the spare request must still read valid memory -> this tile's first source again
+                describe(cur, 0); rebase(cur, 0);
+                xa_n = ximg;
+            }                                  // (single source: the last chunk is requested once more, into the free slot)
             RING_T(t_issue)
             RING_COMPUTE(boff, R_BUF - boff, false)
             RING_T(t_comp)
@@ -389,6 +402,11 @@ bool conv_ring_supported(const ConvKernelCfg& cfg, const ConvParams& p) {
     if ((p.out_mode != OUT_NORMAL && p.out_mode != OUT_POOL) || p.pix_limit != 0 || p.gate != nullptr || p.zeros == nullptr) return false;
     if (p.out_mode == OUT_POOL && (p.act != ACT_RELU || p.res != nullptr)) return false;   // the pool compares bf16 bit patterns: values must be >= 0
     if (p.Cin < 32 || p.Cin % 16 != 0 || p.Cout % 64 != 0 || p.Cout * 4 > R_BIAS_BYTES || p.Ho != p.H || p.Wo != p.W) return false;
+    if (p.n_src > 1) {   // chunks per source >= 2 (the peeled first chunk requests chunk 1 of the same source), whole low-resolution pixels
+        if (p.n_src > 4 || p.Cin % (16 * p.n_src) != 0 || p.Cin / (16 * p.n_src) < 2 || p.x_blk || p.out_mode != OUT_NORMAL) return false;
+        for (int k = 0; k < p.n_src; ++k)
+            if (p.xs[k] == nullptr || p.xs_shift[k] < 0 || p.xs_shift[k] > 3 || p.H % (1 << p.xs_shift[k]) != 0 || p.W % (1 << p.xs_shift[k]) != 0) return false;
+    }
     if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
     if (p.res != nullptr && (p.res_shift != 0 || p.res_h != p.H || p.res_w != p.W || p.res_cstride % 4 != 0 || (long long)p.H * p.W * p.res_cstride >= (1ll << 31))) return false;
     if ((long long)p.H * p.W * (p.Cin > p.y_cstride ? p.Cin : p.y_cstride) >= (1ll << 31)) return false;   // 32-bit per-image offsets

@@ -14,6 +14,8 @@ struct Tensor4 {
     bf16_t* p = nullptr;
     int n = 0, h = 0, w = 0, c = 0;
     bool blk = false;  // channel-blocked layout [n][c/16][h][w][16] instead of NHWC (conv_mfma.h: ConvParams::x_blk)
+    // virtual concat (ConvParams::n_src): the c channels are n_src tensors of c / n_src channels, source k at 1 / 2^shift[k] resolution
+    int n_src = 0; const bf16_t* xs[4] = {nullptr, nullptr, nullptr, nullptr}; int xs_shift[4] = {0, 0, 0, 0};
     size_t elems() const { return (size_t)n * h * w * c; }
 };
 
@@ -99,6 +101,7 @@ struct lumina_ocr {
     int svtr_f16 = -1;      // storage type of the next SVTR load: -1 = what the blob's svtr.config says, 0 bf16, 1 fp16
     int conv2d_variant = 0; // lumina_ocr_conv2d: 0 = the layer's default kernel, 1 = LDS-DMA 16x32 tile, 2 = ring kernel (tests)
     int ring_orient = -1;   // its tile orientation: -1 auto, 0 / 1 forced (tests)
+    bool fpn_multi = true;  // head.conv1 reads p5 / p4 / p3 / p2 at their own resolution (ring kernel): the FPN concat is never written
     bool fuse_stem = true;  // stem.conv1 + stem.conv2 in one kernel (the first 32-channel tensor stays in LDS)
     bool fuse_mb = true;    // recogniser blocks: expand + depthwise in one kernel (the expanded tensor stays in LDS)
     // per-kernel event timing (bench roofline): accumulated conv-kernel time of the last det forward

@@ -223,6 +223,17 @@ int eng_load_det(lumina_ocr* eng, const void* blob, size_t n) {
 }
 
 // ------------------------------------------------------------------------------ conv dispatch
+// does a 3x3 / stride-1 layer on an ho x wo map take the 16x32-tile (LDS-DMA / ring) kernels?  Depends on the layer geometry and the
+// configured sub-batch only, never on the number of images in the call (the variants sum in different orders)
+static bool conv_takes_big(const lumina_ocr* eng, const ConvLayer& L, int n, int ho, int wo, bool flat) {
+    static const bool no_big = getenv("LUMINA_CONV_NO_BIG") != nullptr;
+    static const long long big_min_env = getenv("LUMINA_CONV_BIG_MIN") ? atoll(getenv("LUMINA_CONV_BIG_MIN")) : -1;
+    const long long nb_eff = n > eng->det_sub_batch ? n : eng->det_sub_batch;
+    const long long big_blocks = nb_eff * ((ho + 15) / 16) * ((wo + 31) / 32) * ((L.cout + L.cfg.bn - 1) / L.cfg.bn);
+    const long long big_min = big_min_env >= 0 ? big_min_env : eng->conv_big_min;
+    return (L.force_big && L.wpk_big != nullptr) || (!no_big && !flat && !L.small_only && L.wpk_big != nullptr && big_blocks >= big_min);
+}
+
 int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4* y, const Tensor4* res, int res_shift, int out_mode,
                  int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st, const bf16_t* gate) {
     ConvParams p{};
@@ -250,6 +261,8 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     }
     p.res_shift = res_shift;
     p.x_blk = x.blk; p.y_blk = y->blk; p.res_blk = res ? res->blk : 0;
+    p.n_src = x.n_src;
+    for (int k = 0; k < 4; ++k) { p.xs[k] = x.xs[k]; p.xs_shift[k] = x.xs_shift[k]; }
     p.res_cstride = res ? res->c : 0;
     p.y_cstride = y_cstride ? y_cstride : y->c;
     p.y_coff = y_coff;
@@ -260,22 +273,16 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, st));
     }
-    static const bool no_big = getenv("LUMINA_CONV_NO_BIG") != nullptr;
-    // 16x32 tiles (less LDS and L2 traffic per MFMA) once they still give >= 2 workgroups per CU on all 256 CUs twice over
-    // the variant must not depend on how many images happen to be in this call (the two kernels sum the same products in a
-    // different order): count workgroups for a full sub-batch
-    const long long nb_eff = p.N > eng->det_sub_batch ? p.N : eng->det_sub_batch;
-    const long long big_blocks = nb_eff * ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32) * ((L.cout + L.cfg.bn - 1) / L.cfg.bn);
-    static const long long big_min_env = getenv("LUMINA_CONV_BIG_MIN") ? atoll(getenv("LUMINA_CONV_BIG_MIN")) : -1;
-    const long long big_min = big_min_env >= 0 ? big_min_env : eng->conv_big_min;
     if (out_mode == OUT_POOL && (L.wpk_big == nullptr || L.cfg_big.nw != 6)) return locr_fail(eng, "fused max pool needs the LDS-DMA conv kernel", L.name.c_str());
-    const bool use_big = out_mode == OUT_POOL || (L.force_big && L.wpk_big != nullptr) || (!no_big && !flat && !L.small_only && L.wpk_big != nullptr && big_blocks >= big_min);
+    // 16x32 tiles (less LDS and L2 traffic per MFMA) once they still give >= 2 workgroups per CU on all 256 CUs twice over
+    const bool use_big = out_mode == OUT_POOL || conv_takes_big(eng, L, p.N, p.Ho, p.Wo, flat);
     if (L.force_big && eng->conv2d_variant == 2 && !conv_ring_supported(L.cfg_big, p)) return locr_fail(eng, "conv2d_variant 2: the ring kernel does not take this layer", L.name.c_str());
     ConvKernelCfg cfg = L.cfg;
     if (use_big) { cfg = L.cfg_big; p.wpk = L.wpk_big; }
     static const bool no_pw = getenv("LUMINA_CONV_NO_PW") != nullptr;
     const bool use_pw = !no_pw && !use_big && conv_pw_supported(cfg, p);
     const bool use_ring = eng->conv_ring && use_big && !use_pw && conv_ring_supported(cfg, p);
+    if (p.n_src > 1 && !use_ring) return locr_fail(eng, "a multi-source input reached a kernel other than the ring kernel", L.name.c_str());
     if (!use_ring && (p.x_blk || p.y_blk || p.res_blk)) return locr_fail(eng, "a channel-blocked tensor reached a kernel that cannot address it", L.name.c_str());
     hipError_t e = use_ring ? conv_ring_launch(p, eng->ring_orient, st) : (use_pw ? conv_pw_launch(p, st) : conv_launch(cfg, p, st));
     if (e != hipSuccess) return locr_fail(eng, L.name.c_str(), hipGetErrorString(e));
@@ -285,7 +292,9 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         const double px = flat ? (double)p.pix_limit : (double)p.N * p.Ho * p.Wo;
         eng->conv_flops.push_back(2.0 * px * L.ks * L.ks * L.cin * L.cout);
         // algorithmic HBM bytes: input once + output once (+ residual) + weights once
-        eng->conv_bytes.push_back(2.0 * ((double)x.elems() + px * (out_mode == OUT_CONVT && p.fuse_w ? 4.0 : (double)L.cout) * (out_mode == OUT_UPSAMPLE ? (double)(1 << (2 * up_shift)) : (out_mode == OUT_POOL ? 0.25 : 1.0)) + (res ? px * (double)L.cout / (double)(1 << (2 * res_shift)) : 0.0) + (double)L.ks * L.ks * L.cin * L.cout));
+        double in_elems = (double)x.elems();
+        if (x.n_src > 1) { in_elems = 0; for (int k = 0; k < x.n_src; ++k) in_elems += (double)x.n * (x.h >> x.xs_shift[k]) * (x.w >> x.xs_shift[k]) * (x.c / x.n_src); }
+        eng->conv_bytes.push_back(2.0 * (in_elems + px * (out_mode == OUT_CONVT && p.fuse_w ? 4.0 : (double)L.cout) * (out_mode == OUT_UPSAMPLE ? (double)(1 << (2 * up_shift)) : (out_mode == OUT_POOL ? 0.25 : 1.0)) + (res ? px * (double)L.cout / (double)(1 << (2 * res_shift)) : 0.0) + (double)L.ks * L.ks * L.cin * L.cout));
         eng->conv_names.push_back(L.name);
         std::string kname = use_pw ? (L.cin == 64 ? "conv_pw_kernel<64>" : "conv_pw_kernel<128>") : conv_kernel_name(cfg);
         if (use_ring) kname = out_mode == OUT_POOL ? "conv_ring_kernel<0,false,true>" : (conv_ring_transposed(p, eng->ring_orient) ? "conv_ring_kernel<1>" : "conv_ring_kernel<0>");
@@ -372,15 +381,35 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
     RUN(eng_run_conv(eng, D["fpn.in3"], feats[1], &out3, &out4, 1, OUT_NORMAL, 0, 0, 0, false, st));
     Tensor4 out2 = ws_tensor(eng, B, feats[0].h, feats[0].w, 256);
     RUN(eng_run_conv(eng, D["fpn.in2"], feats[0], &out2, &out3, 1, OUT_NORMAL, 0, 0, 0, false, st));
-    // smooth convs write straight into the channel slices of the 1/4-resolution concat (replicated)
-    Tensor4 fuse = ws_tensor(eng, B, Hp / 4, Wp / 4, 256);
-    RUN(eng_run_conv(eng, D["fpn.p5"], in5, &fuse, nullptr, 0, OUT_UPSAMPLE, 3, 256, 0, false, st));
-    RUN(eng_run_conv(eng, D["fpn.p4"], out4, &fuse, nullptr, 0, OUT_UPSAMPLE, 2, 256, 64, false, st));
-    RUN(eng_run_conv(eng, D["fpn.p3"], out3, &fuse, nullptr, 0, OUT_UPSAMPLE, 1, 256, 128, false, st));
-    RUN(eng_run_conv(eng, D["fpn.p2"], out2, &fuse, nullptr, 0, OUT_NORMAL, 0, 256, 192, false, st));
-    tap(eng, "fpn.fuse", fuse);
+    // DBHead's first conv runs over the concat [up8(p5), up4(p4), up2(p3), p2].  Default: the smoothing convs write p5 .. p2 at their
+    // own resolution and head.conv1 (ring kernel) reads them nearest-upsampled through its halo addressing — the 1/4-resolution
+    // 256-channel concat (1.5 GB per 16 A4 pages, written 4 / 16 / 64-fold replicated) never exists.  Same products, same order.
+    ConvLayer& hc1 = D["head.conv1"];
+    const bool multi = eng->fpn_multi && eng->keep_taps != 1 && eng->conv_ring && conv_takes_big(eng, hc1, B, Hp / 4, Wp / 4, false) &&
+                       (Hp / 4) % 8 == 0 && (Wp / 4) % 8 == 0;
     Tensor4 h1 = ws_tensor(eng, B, Hp / 4, Wp / 4, 64);
-    RUN(eng_run_conv(eng, D["head.conv1"], fuse, &h1, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "head.conv1", h1);
+    if (multi) {
+        Tensor4 p5 = ws_tensor(eng, B, in5.h, in5.w, 64), p4 = ws_tensor(eng, B, out4.h, out4.w, 64);
+        Tensor4 p3 = ws_tensor(eng, B, out3.h, out3.w, 64), p2 = ws_tensor(eng, B, out2.h, out2.w, 64);
+        RUN(eng_run_conv(eng, D["fpn.p5"], in5, &p5, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "fpn.p5", p5);
+        RUN(eng_run_conv(eng, D["fpn.p4"], out4, &p4, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "fpn.p4", p4);
+        RUN(eng_run_conv(eng, D["fpn.p3"], out3, &p3, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "fpn.p3", p3);
+        RUN(eng_run_conv(eng, D["fpn.p2"], out2, &p2, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "fpn.p2", p2);
+        Tensor4 cat = p2;
+        cat.c = 256; cat.n_src = 4;
+        cat.xs[0] = p5.p; cat.xs[1] = p4.p; cat.xs[2] = p3.p; cat.xs[3] = p2.p;
+        cat.xs_shift[0] = 3; cat.xs_shift[1] = 2; cat.xs_shift[2] = 1; cat.xs_shift[3] = 0;
+        RUN(eng_run_conv(eng, hc1, cat, &h1, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "head.conv1", h1);
+    } else {
+        // smooth convs write straight into the channel slices of the 1/4-resolution concat (replicated)
+        Tensor4 fuse = ws_tensor(eng, B, Hp / 4, Wp / 4, 256);
+        RUN(eng_run_conv(eng, D["fpn.p5"], in5, &fuse, nullptr, 0, OUT_UPSAMPLE, 3, 256, 0, false, st));
+        RUN(eng_run_conv(eng, D["fpn.p4"], out4, &fuse, nullptr, 0, OUT_UPSAMPLE, 2, 256, 64, false, st));
+        RUN(eng_run_conv(eng, D["fpn.p3"], out3, &fuse, nullptr, 0, OUT_UPSAMPLE, 1, 256, 128, false, st));
+        RUN(eng_run_conv(eng, D["fpn.p2"], out2, &fuse, nullptr, 0, OUT_NORMAL, 0, 256, 192, false, st));
+        tap(eng, "fpn.fuse", fuse);
+        RUN(eng_run_conv(eng, hc1, fuse, &h1, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "head.conv1", h1);
+    }
     Tensor4 pm; pm.p = prob; pm.n = B; pm.h = Hp; pm.w = Wp; pm.c = 1;
     if (dry) pm.p = nullptr;
     if (eng->fuse_head && eng->keep_taps != 1) {  // DBHead tail in one launch: the 64-channel 1/2-resolution tensor never exists

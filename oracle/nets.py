@@ -133,10 +133,10 @@ def det_forward(wd: Dict[str, np.ndarray], pages_u8: np.ndarray, hp: Optional[in
         out4 = conv_bn_act(c4, wd, "fpn.in4", 1, "none", residual=F.interpolate(in5, scale_factor=2, mode="nearest"), mode=mode)
         out3 = conv_bn_act(c3, wd, "fpn.in3", 1, "none", residual=F.interpolate(out4, scale_factor=2, mode="nearest"), mode=mode)
         out2 = conv_bn_act(c2, wd, "fpn.in2", 1, "none", residual=F.interpolate(out3, scale_factor=2, mode="nearest"), mode=mode)
-        p5 = conv_bn_act(in5, wd, "fpn.p5", 1, "none", mode=mode)
-        p4 = conv_bn_act(out4, wd, "fpn.p4", 1, "none", mode=mode)
-        p3 = conv_bn_act(out3, wd, "fpn.p3", 1, "none", mode=mode)
-        p2 = conv_bn_act(out2, wd, "fpn.p2", 1, "none", mode=mode)
+        p5 = conv_bn_act(in5, wd, "fpn.p5", 1, "none", mode=mode); tap("fpn.p5", p5)
+        p4 = conv_bn_act(out4, wd, "fpn.p4", 1, "none", mode=mode); tap("fpn.p4", p4)
+        p3 = conv_bn_act(out3, wd, "fpn.p3", 1, "none", mode=mode); tap("fpn.p3", p3)
+        p2 = conv_bn_act(out2, wd, "fpn.p2", 1, "none", mode=mode); tap("fpn.p2", p2)
         fuse = torch.cat([F.interpolate(p5, scale_factor=8, mode="nearest"),
                           F.interpolate(p4, scale_factor=4, mode="nearest"),
                           F.interpolate(p3, scale_factor=2, mode="nearest"), p2], dim=1)

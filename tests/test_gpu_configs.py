@@ -17,6 +17,7 @@ def test_config2_det_batch32_1024(engine, det_weights):
     base = np.stack([synth.synth_page(1024, 1024, 1234 + i, n_lines=24)[0] for i in range(4)])
     pages = torch.from_numpy(np.concatenate([base] * 8)).cuda()            # 32 pages, 4 distinct
     engine.load_det(det_weights)
+    engine.set_option("det_sub_batch", 16)                                 # the bench's sub-batch (the kernel choice depends on it)
     engine.set_option("keep_taps", 2)                                      # every fusion stays on; taps of the last sub-batch (pages 16..31)
     engine.set_option("time_convs", 1)
     engine.conv_timing_detail()
@@ -24,7 +25,7 @@ def test_config2_det_batch32_1024(engine, det_weights):
         prob = engine.det_forward(pages)
         torch.cuda.synchronize()
         names = [k for _, k, *_ in engine.conv_timing_detail()]
-        got = {name: engine.read_tap(name)[0] for name in ("s0.b1", "s3.b1", "fpn.fuse", "head.conv1")}   # page 16 == base[0]
+        got = {name: engine.read_tap(name)[0] for name in ("s0.b1", "s3.b1", "fpn.p3", "fpn.p2", "head.conv1")}   # page 16 == base[0]
     finally:
         engine.set_option("keep_taps", 0)
         engine.set_option("time_convs", 0)
@@ -37,7 +38,7 @@ def test_config2_det_batch32_1024(engine, det_weights):
     ref = nets.det_forward(det_weights, base[:1], mode="bf16", taps=taps)  # one full-size page against the oracle, taps included
     for name, g in got.items():
         s_ = close_stats(g, taps[name][0])
-        assert s_["within4"] > 0.90 and s_["mean_abs"] < 0.01 * max(s_["ref_mean_abs"], 1e-3), (name, s_)
+        assert s_["within4"] > (0.85 if name.startswith("fpn.p") else 0.90) and s_["mean_abs"] < 0.01 * max(s_["ref_mean_abs"], 1e-3), (name, s_)
     st = close_stats(prob[0].float().cpu().numpy(), ref[0])
     assert st["within4"] > 0.98 and st["max_abs"] < 0.06, st
     boxes, scores, counts = engine.det_postprocess(prob, 1024, 1024, **arch.TEXT_PATH_POST)

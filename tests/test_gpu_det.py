@@ -21,7 +21,10 @@ def _dump(name, obj):
 
 
 # what still exists with every fusion on (engine option keep_taps=2): all of these are compared bit for bit below
-TAPS_FUSED = ["stem.pool", "s0.b0", "s0.b1", "s1.b0", "s1.b1", "s2.b0", "s2.b1", "s3.b0", "s3.b1", "fpn.fuse", "head.conv1"]
+TAPS_FUSED = ["stem.pool", "s0.b0", "s0.b1", "s1.b0", "s1.b1", "s2.b0", "s2.b1", "s3.b0", "s3.b1", "head.conv1"]
+# the FPN outputs: either the 1/4-resolution concat, or — when head.conv1 reads p5 .. p2 at their own resolution (option fpn_multi, the
+# default wherever the ring kernel serves head.conv1) — the four tensors themselves
+TAPS_FPN = [["fpn.fuse"], ["fpn.p5", "fpn.p4", "fpn.p3", "fpn.p2"]]
 
 
 def _forward_all(engine, pages):
@@ -33,6 +36,13 @@ def _forward_all(engine, pages):
         out = {"prob": prob.view(torch.int16).cpu().numpy()}
         for name in TAPS_FUSED:
             out[name] = engine.read_tap(name)
+        from lumina_ocr.engine import EngineError
+        for group in TAPS_FPN:
+            try:
+                for name in group:
+                    out[name] = engine.read_tap(name)
+            except EngineError:
+                pass
     finally:
         engine.set_option("keep_taps", 0)
     return out
@@ -40,6 +50,8 @@ def _forward_all(engine, pages):
 
 def _assert_same(a, b, what=""):
     for name in a:
+        if name not in b:          # (the two runs materialised the FPN outputs differently: compared through head.conv1 / prob)
+            continue
         assert a[name].shape == b[name].shape, (what, name)
         if not np.array_equal(a[name], b[name]):
             d = np.argwhere(a[name] != b[name])
@@ -60,6 +72,7 @@ def test_det_forward_taps_and_prob(engine, det_weights, shape):
     engine.set_option("det_sub_batch", 8)
     prob = engine.det_forward(torch.from_numpy(pages).cuda())
     torch.cuda.synchronize()
+    engine.set_option("det_sub_batch", 16)
     taps = {}
     ref = nets.det_forward(det_weights, pages, mode="bf16", taps=taps)
     worst = {}
@@ -110,21 +123,51 @@ def test_det_taps_vs_oracle_with_the_production_kernels(engine, any_det_weights,
         engine.set_option("conv_big_min", 1024)
         engine.set_option("conv_ring", 1)
         engine.set_option("time_convs", 0)
+        engine.set_option("det_sub_batch", 16)
     want = "conv_ring_kernel" if ring else "conv_mfma_kernel<3,1,64,16,32,4,3,4>"
     assert sum(k.startswith(want) for k in names) >= 10, names
     assert any(k.startswith("conv_ring_kernel<0,false,true>") or k.endswith(",4,4>") for k in names), names   # pooled stem.conv3
     taps = {}
     ref = nets.det_forward(any_det_weights, pages, mode="bf16", taps=taps)
-    stats = {name: close_stats(got[name], taps[name]) for name in TAPS_FUSED}
+    stats = {name: close_stats(got[name], taps[name]) for name in got if name != "prob"}
+    assert "fpn.fuse" in stats or "fpn.p2" in stats
     p = arch.bf16_bits_to_f32(got["prob"].view(np.uint16))
     stats["prob"] = close_stats(p, ref)
     _dump("parity_det_prod_ring%d_b%d_%dx%d.json" % ((ring,) + shape), stats)
     for name, s_ in stats.items():
         if name != "prob":
             assert got[name].shape == taps[name].shape
-            assert s_["within4"] > 0.90 and s_["mean_abs"] < 0.01 * max(s_["ref_mean_abs"], 1e-3), (name, s_)
+            # (the deepest FPN levels sit behind ~25 bf16-rounded layers: their drift is the largest, ~0.5 % of the mean magnitude)
+            assert s_["within4"] > (0.85 if name.startswith("fpn.p") else 0.90) and s_["mean_abs"] < 0.01 * max(s_["ref_mean_abs"], 1e-3), (name, s_)
     assert stats["stem.pool"]["within1"] > 0.999 and stats["s0.b0"]["within1"] > 0.99, stats
     assert stats["prob"]["within4"] > 0.97 and stats["prob"]["max_abs"] < 0.06, stats["prob"]
+
+
+@pytest.mark.parametrize("orient", [0, 1], ids=["rows", "transposed"])
+@pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901), (3, 352, 512)], ids=lambda s: "b%d_%dx%d" % s)
+def test_head_reads_fpn_maps_at_their_own_resolution_bit_identically(engine, any_det_weights, shape, orient):
+    """Option fpn_multi: head.conv1's halo addressing reads p5 / p4 / p3 / p2 nearest-upsampled from their own tensors (the FPN
+    concat is never written) — the same products in the same order as the conv over the materialised concat."""
+    b, h, w = shape
+    pages = torch.from_numpy(_pages(b, h, w, 51)).cuda()
+    engine.load_det(any_det_weights)
+    engine.set_option("conv_big_min", 1)
+    engine.set_option("ring_orient", orient)
+    try:
+        engine.set_option("fpn_multi", 0)
+        ref = _forward_all(engine, pages)
+        engine.set_option("fpn_multi", 1)
+        a = _forward_all(engine, pages)
+    finally:
+        engine.set_option("fpn_multi", 1)
+        engine.set_option("ring_orient", -1)
+        engine.set_option("conv_big_min", 1024)
+    assert "fpn.fuse" in ref and "fpn.p3" in a and "fpn.fuse" not in a
+    _assert_same(a, ref, "fpn_multi")
+    assert np.array_equal(a["head.conv1"], ref["head.conv1"]) and np.array_equal(a["prob"], ref["prob"])
+    # the four maps are the channel slices of the concat, sub-sampled
+    for k, (name, s_) in enumerate((("fpn.p5", 8), ("fpn.p4", 4), ("fpn.p3", 2), ("fpn.p2", 1))):
+        assert np.array_equal(a[name], ref["fpn.fuse"][:, ::s_, ::s_, 64 * k:64 * k + 64]), name
 
 
 def test_det_sub_batching_is_invisible(engine, any_det_weights):
@@ -134,7 +177,7 @@ def test_det_sub_batching_is_invisible(engine, any_det_weights):
     a = engine.det_forward(pages).clone()
     engine.set_option("det_sub_batch", 2)
     b = engine.det_forward(pages).clone()
-    engine.set_option("det_sub_batch", 4)
+    engine.set_option("det_sub_batch", 16)
     torch.cuda.synchronize()
     assert torch.equal(a.view(torch.int16), b.view(torch.int16))
 
