@@ -383,7 +383,14 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* rgb, uint8_t* 
     long long sx = X >> 5, sy = Y >> 5;
     sx = sx > 32767 ? 32767 : (sx < -32768 ? -32768 : sx);
     sy = sy > 32767 ? 32767 : (sy < -32768 ? -32768 : sy);
-    const short* w = wtab + (size_t)((Y & 31) * 32 + (X & 31)) * 16;
+    short w[16];   // the phase's 4x4 weights: 32 contiguous bytes of the table
+    {
+        const uint4* wp = reinterpret_cast<const uint4*>(wtab + (size_t)((Y & 31) * 32 + (X & 31)) * 16);
+        const uint4 w0 = wp[0], w1 = wp[1];
+        const uint32_t ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { w[2 * k] = (short)(ww[k] & 0xffffu); w[2 * k + 1] = (short)(ww[k] >> 16); }
+    }
     int sum[3] = {0, 0, 0};
     const int bx = (int)sx - 1, by = (int)sy - 1;
     if (bx >= 0 && bx + 4 <= W && by >= 0 && by + 4 <= H && ((size_t)(pg + 1) * H * W * 3 - (((size_t)pg * H + by + 3) * W + bx) * 3) >= 16) {
