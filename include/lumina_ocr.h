@@ -39,7 +39,7 @@ int lumina_ocr_create(int device, lumina_ocr_t** out);
 void lumina_ocr_destroy(lumina_ocr_t* h);
 const char* lumina_ocr_last_error(const lumina_ocr_t* h);
 const char* lumina_ocr_version(void);
-/* options: "det_sub_batch", "rec_sub_batch", "post_group", "keep_taps", "time_convs"; developer A/B switches (results are
+/* options: "det_sub_batch", "rec_sub_batch", "post_group", "tail_group", "keep_taps", "time_convs"; developer A/B switches (results are
  * bit-identical either way): "fuse_head", "fuse_pool", "fuse_stem", "fuse_mb", "fpn_multi", "conv_ring", "ring_orient", "conv_big_min",
  * "blocked_layout" (experiment: fails loudly when a blocked tensor would reach a kernel other than the ring kernel);
  * "svtr_f16" (storage type of the next SVTR load), "conv2d_variant" (kernel choice of lumina_ocr_conv2d, parity tests) */

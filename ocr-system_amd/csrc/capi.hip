@@ -79,6 +79,7 @@ int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value) {
     else if (!strcmp(key, "conv_big_min")) h->conv_big_min = value >= 0 ? value : 1024;
     else if (!strcmp(key, "ring_orient")) h->ring_orient = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "post_group")) h->post_group = value > 0 ? value : 1;
+    else if (!strcmp(key, "tail_group")) h->tail_group = value > 0 ? value : 0;
     else if (!strcmp(key, "svtr_f16")) h->svtr_f16 = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "conv2d_variant")) h->conv2d_variant = value < 0 || value > 2 ? 0 : value;
     else return locr_fail(h, "set_option: unknown key", key);

@@ -236,6 +236,23 @@ static bool conv_takes_big(const lumina_ocr* eng, const ConvLayer& L, int n, int
 
 int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4* y, const Tensor4* res, int res_shift, int out_mode,
                  int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st, const bf16_t* gate) {
+    if (L.launch_group > 0 && x.n > L.launch_group && !flat && gate == nullptr && x.p != nullptr && y->p != nullptr &&
+        (out_mode == OUT_NORMAL) && !x.blk && !y->blk && (!res || !res->blk)) {
+        // the same layer in launches of launch_group images (slices of the NHWC tensors; results are per image, hence identical)
+        ConvLayer one = L;
+        one.launch_group = 0;
+        const size_t ystride = (size_t)y->h * y->w * (y_cstride ? y_cstride : y->c);
+        for (int b0 = 0; b0 < x.n; b0 += L.launch_group) {
+            const int nb = x.n - b0 < L.launch_group ? x.n - b0 : L.launch_group;
+            Tensor4 xs = x, ys = *y, rs;
+            xs.n = nb; xs.p = x.p + (size_t)b0 * x.h * x.w * (x.n_src > 1 ? x.c / x.n_src : x.c);
+            for (int k = 0; k < x.n_src; ++k) xs.xs[k] = x.xs[k] + (size_t)b0 * (x.h >> x.xs_shift[k]) * (x.w >> x.xs_shift[k]) * (x.c / x.n_src);
+            ys.n = nb; ys.p = y->p + (size_t)b0 * ystride;
+            if (res) { rs = *res; rs.n = nb; rs.p = res->p + (size_t)b0 * res->h * res->w * res->c; }
+            if (eng_run_conv(eng, one, xs, &ys, res ? &rs : nullptr, res_shift, out_mode, up_shift, y_cstride, y_coff, flat, st, gate)) return 1;
+        }
+        return 0;
+    }
     ConvParams p{};
     if (eng->zero_block == nullptr) {
         const uint32_t z[64] = {0};
@@ -379,47 +396,64 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
     RUN(eng_run_conv(eng, D["fpn.in4"], feats[2], &out4, &in5, 1, OUT_NORMAL, 0, 0, 0, false, st));
     Tensor4 out3 = ws_tensor(eng, B, feats[1].h, feats[1].w, 256);
     RUN(eng_run_conv(eng, D["fpn.in3"], feats[1], &out3, &out4, 1, OUT_NORMAL, 0, 0, 0, false, st));
-    Tensor4 out2 = ws_tensor(eng, B, feats[0].h, feats[0].w, 256);
-    RUN(eng_run_conv(eng, D["fpn.in2"], feats[0], &out2, &out3, 1, OUT_NORMAL, 0, 0, 0, false, st));
     // DBHead's first conv runs over the concat [up8(p5), up4(p4), up2(p3), p2].  Default: the smoothing convs write p5 .. p2 at their
     // own resolution and head.conv1 (ring kernel) reads them nearest-upsampled through its halo addressing — the 1/4-resolution
     // 256-channel concat (1.5 GB per 16 A4 pages, written 4 / 16 / 64-fold replicated) never exists.  Same products, same order.
     ConvLayer& hc1 = D["head.conv1"];
     const bool multi = eng->fpn_multi && eng->keep_taps != 1 && eng->conv_ring && conv_takes_big(eng, hc1, B, Hp / 4, Wp / 4, false) &&
                        (Hp / 4) % 8 == 0 && (Wp / 4) % 8 == 0;
-    Tensor4 h1 = ws_tensor(eng, B, Hp / 4, Wp / 4, 64);
+    auto slice = [](const Tensor4& t, int b0, int nb) {
+        Tensor4 r = t;
+        r.n = nb;
+        if (t.p) r.p = t.p + (size_t)b0 * t.h * t.w * t.c;
+        return r;
+    };
+    auto head_tail = [&](const Tensor4& h1, bf16_t* prob_g, int nb) -> int {
+        Tensor4 pm; pm.p = dry ? nullptr : prob_g; pm.n = nb; pm.h = Hp; pm.w = Wp; pm.c = 1;
+        if (eng->fuse_head && eng->keep_taps != 1)   // DBHead tail in one launch: the 64-channel 1/2-resolution tensor never exists
+            return eng_run_conv(eng, D["head.convt2.fused"], h1, &pm, nullptr, 0, OUT_CONVT, 0, 1, 0, false, st);
+        Tensor4 h2 = ws_tensor(eng, nb, Hp / 2, Wp / 2, 64);
+        RUN(eng_run_conv(eng, D["head.convt2"], h1, &h2, nullptr, 0, OUT_CONVT, 0, 0, 0, false, st)); tap(eng, "head.convt2", h2);
+        return eng_run_conv(eng, D["head.convt3"], h2, &pm, nullptr, 0, OUT_CONVT1, 0, 1, 0, false, st);
+    };
     if (multi) {
-        Tensor4 p5 = ws_tensor(eng, B, in5.h, in5.w, 64), p4 = ws_tensor(eng, B, out4.h, out4.w, 64);
-        Tensor4 p3 = ws_tensor(eng, B, out3.h, out3.w, 64), p2 = ws_tensor(eng, B, out2.h, out2.w, 64);
+        Tensor4 p5 = ws_tensor(eng, B, in5.h, in5.w, 64), p4 = ws_tensor(eng, B, out4.h, out4.w, 64), p3 = ws_tensor(eng, B, out3.h, out3.w, 64);
         RUN(eng_run_conv(eng, D["fpn.p5"], in5, &p5, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "fpn.p5", p5);
         RUN(eng_run_conv(eng, D["fpn.p4"], out4, &p4, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "fpn.p4", p4);
         RUN(eng_run_conv(eng, D["fpn.p3"], out3, &p3, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "fpn.p3", p3);
-        RUN(eng_run_conv(eng, D["fpn.p2"], out2, &p2, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "fpn.p2", p2);
-        Tensor4 cat = p2;
-        cat.c = 256; cat.n_src = 4;
-        cat.xs[0] = p5.p; cat.xs[1] = p4.p; cat.xs[2] = p3.p; cat.xs[3] = p2.p;
-        cat.xs_shift[0] = 3; cat.xs_shift[1] = 2; cat.xs_shift[2] = 1; cat.xs_shift[3] = 0;
-        RUN(eng_run_conv(eng, hc1, cat, &h1, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "head.conv1", h1);
-    } else {
-        // smooth convs write straight into the channel slices of the 1/4-resolution concat (replicated)
-        Tensor4 fuse = ws_tensor(eng, B, Hp / 4, Wp / 4, 256);
-        RUN(eng_run_conv(eng, D["fpn.p5"], in5, &fuse, nullptr, 0, OUT_UPSAMPLE, 3, 256, 0, false, st));
-        RUN(eng_run_conv(eng, D["fpn.p4"], out4, &fuse, nullptr, 0, OUT_UPSAMPLE, 2, 256, 64, false, st));
-        RUN(eng_run_conv(eng, D["fpn.p3"], out3, &fuse, nullptr, 0, OUT_UPSAMPLE, 1, 256, 128, false, st));
-        RUN(eng_run_conv(eng, D["fpn.p2"], out2, &fuse, nullptr, 0, OUT_NORMAL, 0, 256, 192, false, st));
-        tap(eng, "fpn.fuse", fuse);
-        RUN(eng_run_conv(eng, hc1, fuse, &h1, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "head.conv1", h1);
-    }
-    Tensor4 pm; pm.p = prob; pm.n = B; pm.h = Hp; pm.w = Wp; pm.c = 1;
-    if (dry) pm.p = nullptr;
-    if (eng->fuse_head && eng->keep_taps != 1) {  // DBHead tail in one launch: the 64-channel 1/2-resolution tensor never exists
-        RUN(eng_run_conv(eng, D["head.convt2.fused"], h1, &pm, nullptr, 0, OUT_CONVT, 0, 1, 0, false, st));
+        // The 1/4-resolution tail — lateral in2 (1.5 GB per 16 pages), p2, head.conv1, DBHead tail — runs in groups of tail_group
+        // pages: each consumer then finds part of its producer's output still in the 256 MB Infinity Cache (A/B on one device,
+        // 64 A4 pages in one forward: p2 3.68 -> 3.47 ms, head.conv1 3.32 -> 3.12 ms), and the 256-channel lateral only ever exists for
+        // one group.  Launch order only: results are per page.
+        const int G = (eng->keep_taps == 0 && eng->tail_group > 0 && B > eng->tail_group) ? eng->tail_group : B;
+        Tensor4 out2 = ws_tensor(eng, G, feats[0].h, feats[0].w, 256), p2 = ws_tensor(eng, G, feats[0].h, feats[0].w, 64);
+        Tensor4 h1 = ws_tensor(eng, G, Hp / 4, Wp / 4, 64);
+        for (int g0 = 0; g0 < B; g0 += G) {
+            const int nb = B - g0 < G ? B - g0 : G;
+            Tensor4 o2 = slice(out2, 0, nb), p2g = slice(p2, 0, nb), h1g = slice(h1, 0, nb), o3 = slice(out3, g0, nb);
+            RUN(eng_run_conv(eng, D["fpn.in2"], slice(feats[0], g0, nb), &o2, &o3, 1, OUT_NORMAL, 0, 0, 0, false, st));
+            RUN(eng_run_conv(eng, D["fpn.p2"], o2, &p2g, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "fpn.p2", p2g);
+            Tensor4 cat = p2g;
+            cat.c = 256; cat.n_src = 4;
+            cat.xs[0] = slice(p5, g0, nb).p; cat.xs[1] = slice(p4, g0, nb).p; cat.xs[2] = slice(p3, g0, nb).p; cat.xs[3] = p2g.p;
+            cat.xs_shift[0] = 3; cat.xs_shift[1] = 2; cat.xs_shift[2] = 1; cat.xs_shift[3] = 0;
+            RUN(eng_run_conv(eng, hc1, cat, &h1g, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "head.conv1", h1g);
+            RUN(head_tail(h1g, prob ? prob + (size_t)g0 * Hp * Wp : nullptr, nb));
+        }
         return 0;
     }
-    Tensor4 h2 = ws_tensor(eng, B, Hp / 2, Wp / 2, 64);
-    RUN(eng_run_conv(eng, D["head.convt2"], h1, &h2, nullptr, 0, OUT_CONVT, 0, 0, 0, false, st)); tap(eng, "head.convt2", h2);
-    RUN(eng_run_conv(eng, D["head.convt3"], h2, &pm, nullptr, 0, OUT_CONVT1, 0, 1, 0, false, st));
-    return 0;
+    Tensor4 out2 = ws_tensor(eng, B, feats[0].h, feats[0].w, 256);
+    RUN(eng_run_conv(eng, D["fpn.in2"], feats[0], &out2, &out3, 1, OUT_NORMAL, 0, 0, 0, false, st));
+    // smooth convs write straight into the channel slices of the 1/4-resolution concat (replicated)
+    Tensor4 fuse = ws_tensor(eng, B, Hp / 4, Wp / 4, 256);
+    RUN(eng_run_conv(eng, D["fpn.p5"], in5, &fuse, nullptr, 0, OUT_UPSAMPLE, 3, 256, 0, false, st));
+    RUN(eng_run_conv(eng, D["fpn.p4"], out4, &fuse, nullptr, 0, OUT_UPSAMPLE, 2, 256, 64, false, st));
+    RUN(eng_run_conv(eng, D["fpn.p3"], out3, &fuse, nullptr, 0, OUT_UPSAMPLE, 1, 256, 128, false, st));
+    RUN(eng_run_conv(eng, D["fpn.p2"], out2, &fuse, nullptr, 0, OUT_NORMAL, 0, 256, 192, false, st));
+    tap(eng, "fpn.fuse", fuse);
+    Tensor4 h1 = ws_tensor(eng, B, Hp / 4, Wp / 4, 64);
+    RUN(eng_run_conv(eng, hc1, fuse, &h1, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "head.conv1", h1);
+    return head_tail(h1, prob, B);
 }
 
 int eng_det_forward(lumina_ocr* eng, const uint8_t* pages, int B, int H, int W, int Hp, int Wp, bf16_t* prob, hipStream_t st) {

@@ -170,6 +170,29 @@ def test_head_reads_fpn_maps_at_their_own_resolution_bit_identically(engine, any
         assert np.array_equal(a[name], ref["fpn.fuse"][:, ::s_, ::s_, 64 * k:64 * k + 64]), name
 
 
+def test_grouped_quarter_resolution_tail_is_invisible(engine, any_det_weights):
+    """Option tail_group: the lateral in2 -> p2 -> head.conv1 -> DBHead tail section runs in groups of pages inside one forward
+    (producer -> consumer locality in the Infinity Cache; the 256-channel lateral exists for one group only): launch order only."""
+    pages = torch.from_numpy(_pages(5, 250, 330, 61)).cuda()
+    engine.load_det(any_det_weights)
+    engine.set_option("conv_big_min", 1)          # head.conv1 on the ring kernel: the multi-source path the grouping belongs to
+    try:
+        engine.set_option("tail_group", 0)
+        ref = engine.det_forward(pages).clone()
+        engine.set_option("tail_group", 2)        # groups of 2 + 2 + 1 pages
+        a = engine.det_forward(pages).clone()
+        engine.set_option("fuse_head", 0)         # (the two-launch DBHead tail inside the group loop)
+        b = engine.det_forward(pages).clone()
+    finally:
+        engine.set_option("fuse_head", 1)
+        engine.set_option("tail_group", 16)
+        engine.set_option("conv_big_min", 1024)
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref)
+    d = (a.float() - b.float()).abs()
+    assert float(d.max()) <= 2.0 ** -8            # fused vs two-launch tail: see test_fused_head_equals_unfused
+
+
 def test_det_sub_batching_is_invisible(engine, any_det_weights):
     pages = torch.from_numpy(_pages(5, 128, 160, 3)).cuda()
     engine.load_det(any_det_weights)
