@@ -463,7 +463,11 @@ void deskew_weight_table(short* wtab) {
                         if (it[k] < it[mk]) mk = k;
                         else if (it[k] > it[Mk]) Mk = k;
                     }
-                if (diff < 0) it[Mk] = (short)(it[Mk] - diff); else it[mk] = (short)(it[mk] - diff);
+                /* the corrected weight saturates like the others: at phase (0, 0) the centre weight is 2^15, stored as 32767 — (src * 32767 +
+                   2^14) >> 15 == src for every byte, an integer-aligned pixel is copied exactly (a wrap to -32768 would negate it) */
+                int fixed = diff < 0 ? it[Mk] - diff : it[mk] - diff;
+                fixed = fixed > 32767 ? 32767 : (fixed < -32768 ? -32768 : fixed);
+                if (diff < 0) it[Mk] = (short)fixed; else it[mk] = (short)fixed;
             }
         }
 }

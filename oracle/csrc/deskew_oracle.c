@@ -44,7 +44,8 @@
  *  5. warpAffine(INTER_CUBIC, BORDER_REPLICATE) in OpenCV's fixed point: M = getRotationMatrix2D((W/2, H/2), angle, 1),
  *     inverted as warpAffine inverts it; X = (rint((M1 y + M2) 1024) + 16 + rint(M0 x 1024)) >> 5 (same for Y), source
  *     pixel (X >> 5, Y >> 5), 32 x 32 sub-pixel phases; 4x4 bicubic weights (A = -0.75) as 15-bit shorts, the products of the
- *     float 1-D tables, their sum forced to 2^15 on the largest (smallest) of the central 2x2 weights;
+ *     float 1-D tables, their sum forced to 2^15 on the largest (smallest) of the central 2x2 weights (saturating at 32767, so that
+ *     an integer-aligned source pixel is copied exactly);
  *     dst = saturate_u8((sum + 2^14) >> 15), source coordinates clamped to the image.
  */
 #include <math.h>
@@ -276,7 +277,11 @@ void oracle_deskew_wtab(int16_t* wtab) {
                         if (it[k] < it[mk]) mk = k;
                         else if (it[k] > it[Mk]) Mk = k;
                     }
-                if (diff < 0) it[Mk] = (int16_t)(it[Mk] - diff); else it[mk] = (int16_t)(it[mk] - diff);
+                /* the corrected weight saturates like the others: at phase (0, 0) the centre weight is 2^15, stored as 32767 — (src * 32767 +
+                   2^14) >> 15 == src for every byte, an integer-aligned pixel is copied exactly (a wrap to -32768 would negate it) */
+                int fixed = diff < 0 ? it[Mk] - diff : it[mk] - diff;
+                fixed = fixed > 32767 ? 32767 : (fixed < -32768 ? -32768 : fixed);
+                if (diff < 0) it[Mk] = (int16_t)fixed; else it[mk] = (int16_t)fixed;
             }
         }
 }
