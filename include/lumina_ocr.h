@@ -94,6 +94,13 @@ int lumina_ocr_resize_lanczos(lumina_ocr_t* h, const uint8_t* in_dev, int n, int
 int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, float contrast, float sharpness,
                        uint8_t* tmp_dev, uint8_t* out_dev, void* stream);
 
+/* binarize (image_preprocessing.py:175-185) / adaptive_binarize (:462-494; settings.PREPROCESSING_APPLY_BINARIZE, off by default,
+ * replaces contrast + sharpness when on: :613-622).  adaptive = 0: PIL L > threshold (what the reference's adaptive_binarize degrades
+ * to without OpenCV, :473-475; byte-exact with it); adaptive = 1: cv2.adaptiveThreshold(GAUSSIAN_C, BINARY, blockSize 11, C 2)
+ * restated ("parity unpinned").  RGB uint8 [n,H,W,3] in; the 0 / 255 value on all three channels out. */
+int lumina_ocr_binarize(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, int adaptive, int threshold, uint8_t* out_dev,
+                        void* stream);
+
 /* deskew (image_preprocessing.py:372-460; on by default in the provider: backend/config.py:85, ocr_service.py:412-417): Canny(50, 150)
  * -> Hough line segments (threshold 100, min length 100, max gap 10) -> median of the segment angles folded into [-45, 45] ->
  * unchanged below 0.5 / above 45 degrees -> cubic affine warp about (W / 2, H / 2) with replicated borders.  The reference does

@@ -336,6 +336,13 @@ int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int heigh
     return e == hipSuccess ? 0 : locr_fail(h, "enhance", hipGetErrorString(e));
 }
 
+int lumina_ocr_binarize(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, int adaptive, int threshold, uint8_t* out_dev, void* stream) {
+    if (!h || !img_dev || !out_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "binarize", "bad arguments");
+    BIND(h);
+    hipError_t e = binarize_launch(img_dev, out_dev, n, height, width, adaptive != 0, threshold, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : locr_fail(h, "binarize", hipGetErrorString(e));
+}
+
 int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, int optimize,
                            uint8_t* out_dev, size_t out_stride, int32_t* sizes_dev, void* stream) {
     if (!h || !pages_dev || !out_dev || !sizes_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "jpeg_encode", "bad arguments");

@@ -12,3 +12,6 @@ hipError_t resample_launch(const uint8_t* in, uint8_t* out, const int* bounds_de
 // contrast (mean-gray blend) then sharpness (3x3 smooth blend) on RGB u8 [N,H,W,3]; tmp = scratch of the same size.
 hipError_t enhance_launch(const uint8_t* img, uint8_t* tmp, uint8_t* out, unsigned long long* sums_dev, int N, int H, int W, float contrast,
                           float sharpness, hipStream_t st);
+// binarisation (image_preprocessing.py:175-185 / :462-494): adaptive = 0: L > threshold; 1: Gaussian 11x11 adaptive threshold, C = 2.
+// RGB u8 [N,H,W,3] in, the 0 / 255 value on all three channels out.
+hipError_t binarize_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, int adaptive, int threshold, hipStream_t st);

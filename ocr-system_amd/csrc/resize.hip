@@ -437,6 +437,65 @@ hipError_t resample_launch(const uint8_t* in, uint8_t* out, const int* bounds_de
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------- binarisation
+// image_preprocessing.py:175-185 (`binarize`: L > 128, what the reference's adaptive_binarize degrades to without OpenCV, :473-475)
+// and :462-494 (`adaptive_binarize`: cv2.adaptiveThreshold(gray, 255, GAUSSIAN_C, BINARY, 11, 2), restated in oracle/preprocess.py).
+// L = PIL's convert('L'): (19595 R + 38470 G + 7471 B + 0x8000) >> 16.  Output: the 0 / 255 value on all three channels.
+namespace {
+constexpr int BZ_TH = 16, BZ_TW = 64, BZ_R = 5;
+__constant__ float c_gauss11[11] = {0x1.20c256p-7f, 0x1.bcb86ap-6f, 0x1.0ab50ap-4f, 0x1.f2464cp-4f, 0x1.6a7e1ep-3f, 0x1.9ac20ap-3f,
+                                    0x1.6a7e1ep-3f, 0x1.f2464cp-4f, 0x1.0ab50ap-4f, 0x1.bcb86ap-6f, 0x1.20c256p-7f};
+__device__ __forceinline__ int lum_L(const uint8_t* p) { return (19595 * p[0] + 38470 * p[1] + 7471 * p[2] + 0x8000) >> 16; }
+
+__global__ __launch_bounds__(256) void binarize_kernel(const uint8_t* img, uint8_t* out, int H, int W, int adaptive, int threshold) {
+    __shared__ uint8_t sL[(BZ_TH + 2 * BZ_R) * (BZ_TW + 2 * BZ_R)];
+    __shared__ float sRow[(BZ_TH + 2 * BZ_R) * BZ_TW];
+    const int pg = blockIdx.z, y0 = blockIdx.y * BZ_TH, x0 = blockIdx.x * BZ_TW, tid = threadIdx.x;
+    const uint8_t* src = img + (size_t)pg * H * W * 3;
+    uint8_t* dst = out + (size_t)pg * H * W * 3;
+    constexpr int LW = BZ_TW + 2 * BZ_R, LH = BZ_TH + 2 * BZ_R;
+    if (!adaptive) {
+        for (int i = tid; i < BZ_TH * BZ_TW; i += 256) {
+            const int y = y0 + i / BZ_TW, x = x0 + i % BZ_TW;
+            if (y >= H || x >= W) continue;
+            const uint8_t v = lum_L(src + ((size_t)y * W + x) * 3) > threshold ? 255 : 0;
+            uint8_t* o = dst + ((size_t)y * W + x) * 3;
+            o[0] = v; o[1] = v; o[2] = v;
+        }
+        return;
+    }
+    for (int i = tid; i < LH * LW; i += 256) {   // L tile with replicated borders
+        const int y = min(max(y0 - BZ_R + i / LW, 0), H - 1), x = min(max(x0 - BZ_R + i % LW, 0), W - 1);
+        sL[i] = (uint8_t)lum_L(src + ((size_t)y * W + x) * 3);
+    }
+    __syncthreads();
+    for (int i = tid; i < LH * BZ_TW; i += 256) {   // horizontal pass: taps in ascending order, one multiply and one add each
+        const int r = i / BZ_TW, c = i % BZ_TW;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) acc = __fadd_rn(acc, __fmul_rn((float)sL[r * LW + c + k], c_gauss11[k]));
+        sRow[i] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < BZ_TH * BZ_TW; i += 256) {
+        const int r = i / BZ_TW, c = i % BZ_TW, y = y0 + r, x = x0 + c;
+        if (y >= H || x >= W) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) acc = __fadd_rn(acc, __fmul_rn(sRow[(r + k) * BZ_TW + c], c_gauss11[k]));
+        const int mean = min(max((int)rintf(acc), 0), 255);
+        const uint8_t v = ((int)sL[(r + BZ_R) * LW + c + BZ_R] - mean > -2) ? 255 : 0;
+        uint8_t* o = dst + ((size_t)y * W + x) * 3;
+        o[0] = v; o[1] = v; o[2] = v;
+    }
+}
+}  // namespace
+
+hipError_t binarize_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, int adaptive, int threshold, hipStream_t st) {
+    hipLaunchKernelGGL(binarize_kernel, dim3((W + BZ_TW - 1) / BZ_TW, (H + BZ_TH - 1) / BZ_TH, N), dim3(256), 0, st, img, out, H, W, adaptive, threshold);
+    return hipGetLastError();
+}
+
 hipError_t enhance_launch(const uint8_t* img, uint8_t* tmp, uint8_t* out, unsigned long long* sums_dev, int N, int H, int W, float contrast,
                           float sharpness, hipStream_t st) {
     hipError_t e = hipMemsetAsync(sums_dev, 0, sizeof(unsigned long long) * N, st);

@@ -71,6 +71,7 @@ def load_library() -> ctypes.CDLL:
         "lumina_ocr_svtr_forward": (i32, [vp, vp, vp, i32, vp, vp, vp]),
         "lumina_ocr_svtr_num_classes": (i32, [vp]),
         "lumina_ocr_svtr_dtype": (i32, [vp]),
+        "lumina_ocr_binarize": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
         "lumina_ocr_deskew": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "lumina_ocr_deskew_warp": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     }
@@ -94,7 +95,7 @@ EXPORTED_SYMBOLS = [
     "lumina_ocr_det_forward", "lumina_ocr_det_postprocess", "lumina_ocr_rec_crop", "lumina_ocr_rec_forward",
     "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing", "lumina_ocr_conv_timing_detail",
     "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients",
-    "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward", "lumina_ocr_svtr_num_classes", "lumina_ocr_svtr_dtype", "lumina_ocr_deskew", "lumina_ocr_deskew_warp",
+    "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward", "lumina_ocr_svtr_num_classes", "lumina_ocr_svtr_dtype", "lumina_ocr_binarize", "lumina_ocr_deskew", "lumina_ocr_deskew_warp",
 ]
 
 
@@ -353,6 +354,16 @@ class Engine:
         the detected angle when the page was rotated or left alone below 0.5 degrees, 0.0 otherwise.  Synchronises."""
         r = rot.cpu().numpy() if hasattr(rot, "cpu") else np.asarray(rot)
         return [float(np.degrees(np.arctan2(s, c))) if int(f) in (1, 3) else 0.0 for s, c, f in r]
+
+    def binarize(self, img, adaptive: bool = True, threshold: int = 128):
+        """image_preprocessing.py:462-494 (adaptive=True: Gaussian 11x11 adaptive threshold, C = 2) / :175-185 (adaptive=False: L > threshold,
+        the reference's behaviour without OpenCV).  uint8 [n,H,W,3] device -> 0 / 255 on all three channels."""
+        torch = _torch()
+        n, h, w, c = img.shape
+        assert c == 3 and img.dtype == torch.uint8
+        out = torch.empty_like(img)
+        self._chk(self.lib.lumina_ocr_binarize(self._h, _ptr(img), n, h, w, int(bool(adaptive)), int(threshold), _ptr(out), self._stream()))
+        return out
 
     def enhance(self, img, contrast: float = 1.2, sharpness: float = 1.1):
         torch = _torch()

@@ -55,6 +55,7 @@ class OcrPipeline:
         assert recognizer in ("crnn", "svtr")
         self.recognizer = recognizer
         self.gather = gather
+        self.binarize = None     # None | "adaptive" (cv2.adaptiveThreshold semantics) | "simple" (L > 128: the reference without OpenCV)
         self.eng = engine
         self.charset = charset or arch.ctc_charset(engine.num_classes or 6625)
         self._decoder = arch.TextDecoder(self.charset)   # class ids -> strings (vectorised for single-code-point dictionaries)
@@ -70,6 +71,8 @@ class OcrPipeline:
         x = pages if (nw, nh) == (w, h) else self.eng.resize_lanczos(pages, nh, nw)
         if deskew:
             x, self.last_skew_angles = self.eng.deskew(x)
+        if self.binarize:        # (:613-622) binarisation replaces contrast + sharpness
+            return self.eng.binarize(x, adaptive=self.binarize == "adaptive")
         return self.eng.enhance(x, 1.2, 1.1) if enhance else x
 
     def detect(self, processed):

@@ -103,6 +103,10 @@ class OCRService:
         self.max_dimension = int(os.environ.get("OCR_MAX_IMAGE_DIMENSION", 2000))
         # settings.OCR_APPLY_DESKEW (/root/reference/backend/config.py:85, default True; used at ocr_service.py:150, :412-417)
         self.apply_deskew = os.environ.get("OCR_APPLY_DESKEW", "true").lower() not in ("0", "false", "no")
+        # settings.PREPROCESSING_APPLY_BINARIZE (ocr_service.py:151, default False): "true" / "adaptive" = cv2.adaptiveThreshold semantics,
+        # "simple" = the L > 128 threshold the reference falls back to without OpenCV (image_preprocessing.py:473-475)
+        b = os.environ.get("PREPROCESSING_APPLY_BINARIZE", "false").lower()
+        self.apply_binarize = "adaptive" if b in ("1", "true", "yes", "adaptive") else ("simple" if b == "simple" else None)
         self._device = int(os.environ.get("LUMINA_OCR_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self._det_weights = os.environ.get("LUMINA_OCR_DET_WEIGHTS", "")
         self._rec_weights = os.environ.get("LUMINA_OCR_REC_WEIGHTS", "")
@@ -167,6 +171,7 @@ class OCRService:
             self._weights_kind = kind
             self._engine = eng
             self._pre._engine = eng
+            pipeline.binarize = self.apply_binarize
             self._pipeline = pipeline
 
     def _device_ctx(self):
@@ -309,7 +314,7 @@ class OCRService:
     # ---- status (:759-795) ----
     def get_status(self) -> Dict[str, Any]:
         st = {"client_initialized": self._pipeline is not None, "model_id": "dbnet-r18vd+crnn-mv3", "max_dimension": self.max_dimension,
-              "device": self._device, "weights": self._weights_kind, "recognizer": self._recognizer, "apply_deskew": self.apply_deskew, "engine": "Lumina MI355X det+rec (HIP, gfx950)"}
+              "device": self._device, "weights": self._weights_kind, "recognizer": self._recognizer, "apply_deskew": self.apply_deskew, "apply_binarize": bool(self.apply_binarize), "engine": "Lumina MI355X det+rec (HIP, gfx950)"}
         if self._engine is not None:
             st["engine_version"] = self._engine.version()
             st["num_classes"] = self._engine.num_classes

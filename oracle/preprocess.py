@@ -165,3 +165,45 @@ def optimize_for_ocr(img: np.ndarray, max_dim: int = MAX_DIM, contrast: float = 
     x = resize_if_needed(img, max_dim)
     x = enhance_contrast(x, contrast)
     return enhance_sharpness(x, sharpness)
+
+
+# --------------------------------------------------------------------------------------
+# binarisation (reference: backend/utils/image_preprocessing.py:175-185 `binarize`, :462-494 `adaptive_binarize`; off by default,
+# settings.PREPROCESSING_APPLY_BINARIZE -> preprocess_for_azure(apply_binarize=...), :613-622)
+# --------------------------------------------------------------------------------------
+def gray_L(img: np.ndarray) -> np.ndarray:
+    """PIL image.convert('L'): (R*19595 + G*38470 + B*7471 + 0x8000) >> 16."""
+    if img.ndim == 2:
+        return img.astype(np.uint8)
+    r, g, b = (img[..., i].astype(np.int64) for i in range(3))
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def binarize(img: np.ndarray, threshold: int = 128) -> np.ndarray:
+    """`binarize` (:175-185) — what the reference's adaptive_binarize falls back to without OpenCV (:473-475), i.e. what it computes
+    in this container: L > threshold -> 255 else 0.  PINNED by tests/golden/preprocess_vectors.npz (binarize*)."""
+    return np.where(gray_L(img) > threshold, 255, 0).astype(np.uint8)
+
+
+# (float)(exp(-(i - 5)^2 / (2 sigma^2)) / sum), sigma = 0.3 * ((11 - 1) * 0.5 - 1) + 0.8 = 2.0: cv2.getGaussianKernel(11, -1, CV_32F)
+GAUSS11 = np.array([float.fromhex(v) for v in (
+    "0x1.20c256p-7", "0x1.bcb86ap-6", "0x1.0ab50ap-4", "0x1.f2464cp-4", "0x1.6a7e1ep-3", "0x1.9ac20ap-3",
+    "0x1.6a7e1ep-3", "0x1.f2464cp-4", "0x1.0ab50ap-4", "0x1.bcb86ap-6", "0x1.20c256p-7")], np.float32)
+
+
+def adaptive_binarize(img: np.ndarray) -> np.ndarray:
+    """cv2.adaptiveThreshold(gray, 255, ADAPTIVE_THRESH_GAUSSIAN_C, THRESH_BINARY, blockSize=11, C=2) (:485-491) restated — OpenCV is
+    absent offline: "parity unpinned".  mean = 11x11 Gaussian of the L image (separable, float32, taps in ascending order, one mul
+    and one add per tap, replicated border, rounded to uint8 once); dst = 255 where L - mean > -2, else 0."""
+    L = gray_L(img)
+    h, w = L.shape
+    f = np.pad(L.astype(np.float32), ((0, 0), (5, 5)), mode="edge")
+    row = np.zeros((h, w), np.float32)
+    for k in range(11):
+        row = (row + (f[:, k:k + w] * GAUSS11[k]).astype(np.float32)).astype(np.float32)
+    f2 = np.pad(row, ((5, 5), (0, 0)), mode="edge")
+    acc = np.zeros((h, w), np.float32)
+    for k in range(11):
+        acc = (acc + (f2[k:k + h, :] * GAUSS11[k]).astype(np.float32)).astype(np.float32)
+    mean = np.clip(np.rint(acc), 0, 255).astype(np.int32)
+    return np.where(L.astype(np.int32) - mean > -2, 255, 0).astype(np.uint8)

@@ -45,3 +45,30 @@ def test_a4_200dpi_page_hashes():
     assert hashlib.sha256(res.tobytes()).hexdigest() == a4["resize_sha256"]
     opt = P.enhance_sharpness(P.enhance_contrast(res, 1.2), 1.1)
     assert hashlib.sha256(opt.tobytes()).hexdigest() == a4["optimize_sha256"]
+
+
+def test_binarize_restatement_matches_the_reference_vectors():
+    """`binarize` (image_preprocessing.py:175-185) — also what the reference's `adaptive_binarize` (:462-494) returns in this container,
+    where OpenCV is absent (:473-475): both captured by tools/make_golden.py."""
+    from oracle import preprocess as op
+    g = np.load(Path(__file__).parent / "golden" / "preprocess_vectors.npz")
+    for i in range(7):
+        assert np.array_equal(op.binarize(g["in%d" % i]), g["binarize%d" % i])
+        assert np.array_equal(g["adaptive_nocv%d" % i], g["binarize%d" % i])
+
+
+def test_adaptive_binarize_restatement_against_an_independent_gaussian():
+    """cv2.adaptiveThreshold(GAUSSIAN_C, 11, 2) restated (parity unpinned: no OpenCV offline).  Cross-check of the restatement's
+    indexing / borders / threshold rule with scipy's separable Gaussian correlation (another summation order: the rounded mean may
+    differ by one grey level on a few pixels)."""
+    from scipy import ndimage
+    from oracle import preprocess as op
+    g = np.load(Path(__file__).parent / "golden" / "preprocess_vectors.npz")
+    for i in (0, 2, 6):
+        img = g["in%d" % i]
+        L = op.gray_L(img).astype(np.float32)
+        m = ndimage.correlate1d(ndimage.correlate1d(L, op.GAUSS11, axis=1, mode="nearest"), op.GAUSS11, axis=0, mode="nearest")
+        ref = np.where(L - np.clip(np.rint(m), 0, 255) > -2, 255, 0).astype(np.uint8)
+        got = op.adaptive_binarize(img)
+        assert got.shape == ref.shape and (got != ref).mean() < 0.005, float((got != ref).mean())
+    assert abs(float(op.GAUSS11.sum()) - 1.0) < 1e-6 and np.array_equal(op.GAUSS11, op.GAUSS11[::-1])

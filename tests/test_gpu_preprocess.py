@@ -94,3 +94,33 @@ def test_resize_alignment_cases_vs_oracle(engine, case):
     big = torch.from_numpy(np.concatenate([np.zeros(3, np.uint8), x.reshape(-1)])).cuda()
     got2 = engine.resize_lanczos(big[3:].view(n, h, w, 3), oh, ow).cpu().numpy()
     assert np.array_equal(got2, got)
+
+
+def test_binarize_simple_is_the_reference_and_adaptive_matches_its_restatement(engine):
+    """image_preprocessing.py:175-185 / :462-494.  simple (L > 128) == the reference's own output in this container (its
+    adaptive_binarize falls back to it without OpenCV): pinned by tests/golden (binarize*, adaptive_nocv*).  adaptive == the
+    restatement of cv2.adaptiveThreshold (oracle/preprocess.py; parity unpinned), bit for bit incl. borders and ragged tiles."""
+    from oracle import preprocess as op
+    g = np.load(Path(__file__).parent / "golden" / "preprocess_vectors.npz")
+    for i in range(7):
+        img = g["in%d" % i]
+        rgb = img if img.ndim == 3 else np.stack([img] * 3, -1)
+        d = torch.from_numpy(np.ascontiguousarray(rgb[None])).cuda()
+        simple = engine.binarize(d, adaptive=False)[0].cpu().numpy()
+        adaptive = engine.binarize(d, adaptive=True)[0].cpu().numpy()
+        assert np.array_equal(simple[..., 0], simple[..., 1]) and np.array_equal(simple[..., 0], simple[..., 2])
+        if img.ndim == 3:      # (an L image converted to RGB and back gives the same L: checked for the RGB cases through the reference)
+            assert np.array_equal(simple[..., 0], g["binarize%d" % i]) and np.array_equal(g["adaptive_nocv%d" % i], g["binarize%d" % i])
+        assert np.array_equal(simple[..., 0], op.binarize(rgb))
+        assert np.array_equal(adaptive[..., 0], op.adaptive_binarize(rgb)), i
+        assert np.array_equal(adaptive[..., 0], adaptive[..., 2])
+    page = np.stack([synth_page_for_binarize(k) for k in range(2)])
+    out = engine.binarize(torch.from_numpy(page).cuda(), adaptive=True).cpu().numpy()
+    for k in range(2):
+        assert np.array_equal(out[k, ..., 0], op.adaptive_binarize(page[k]))
+        assert 0.5 < (out[k] == 255).mean() < 0.99         # text on paper: mostly white, ink black
+
+
+def synth_page_for_binarize(k):
+    from lumina_ocr import synth
+    return synth.synth_page(333, 517, 40 + k, n_lines=8)[0]

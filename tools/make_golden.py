@@ -73,6 +73,9 @@ def main():
         cases[f"contrast{i}"] = np.asarray(small.enhance_contrast(im, factor=1.2))
         cases[f"sharp{i}"] = np.asarray(small.enhance_sharpness(im, factor=1.1))
         cases[f"optimize{i}"] = np.asarray(small.optimize_for_ocr(im))
+        # binarize (:175-185) and what adaptive_binarize (:462-494) computes in this container (no OpenCV: it falls back to binarize)
+        cases[f"binarize{i}"] = np.asarray(small.binarize(im).convert("L"))
+        cases[f"adaptive_nocv{i}"] = np.asarray(small.adaptive_binarize(im).convert("L"))
     np.savez_compressed(OUT / "preprocess_vectors.npz", **cases)
 
     # ---- 3. full-size A4 @ 200 DPI page: hash + a crop (pins the 1654x2339 -> 1414x2000 case BASELINE names) ----
