@@ -98,7 +98,7 @@ struct lumina_ocr {
     bool fuse_head = true;  // head.convt3 fused into head.convt2's epilogue
     bool fuse_pool = true;  // stem.conv3's epilogue does the 3x3/s2 max pool
     int conv_big_min = 1024;  // 16x32-tile kernels once a full sub-batch gives at least this many work-groups
-    bool blocked_layout = false;  // stage-0 activations in channel-blocked layout (experiment)
+    bool blocked_layout = true;   // stage-0 activations between ring-kernel layers in channel-blocked layout (bit-identical)
     bool conv_ring = true;  // persistent ring kernel for the 3x3 / stride-1 layers (conv_ring.hip)
     int svtr_f16 = -1;      // storage type of the next SVTR load: -1 = what the blob's svtr.config says, 0 bf16, 1 fp16
     int conv2d_variant = 0; // lumina_ocr_conv2d: 0 = the layer's default kernel, 1 = LDS-DMA 16x32 tile, 2 = ring kernel (tests)

@@ -373,7 +373,10 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
             const std::string p = "s" + std::to_string(i) + ".b" + std::to_string(j);
             const int stride = (i > 0 && j == 0) ? 2 : 1;
             Tensor4 y = ws_tensor(eng, B, x.h / stride, x.w / stride, chs[i]);
-            const bool blk = i == 0 && eng->blocked_layout && eng->keep_taps == 0;   // stage-0 tensors that only the ring kernel touches
+            // stage-0 tensors that only the ring kernel touches are stored channel-blocked [n][C/16][H][W][16]: a 16-channel chunk
+            // pass then reads / writes whole cache lines (NHWC: 32 of every 128 bytes per pass); same values, DESIGN.md 3.2
+            const bool blk = i == 0 && eng->blocked_layout && eng->keep_taps == 0 && eng->conv_ring && !dry &&
+                             conv_takes_big(eng, D[p + ".conv0"], B, x.h, x.w, false) && conv_takes_big(eng, D[p + ".conv1"], B, x.h, x.w, false);
             y.blk = blk;
             RUN(eng_run_conv(eng, D[p + ".conv0"], x, &y, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st));
             Tensor4 sc = x;
