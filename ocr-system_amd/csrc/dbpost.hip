@@ -5,14 +5,14 @@
 // No reference counterpart; output shape = the 4-point quad of
 // /root/reference/backend/utils/ocr_postprocessor.py:24 / flat polygon of ocr_service.py:295-301.
 //
-// Pipeline (all stream-ordered kernels, no host round trip):
-//   1 ccl_init      one wave per page row: threshold -> label = index of the run start (or -1)
-//   2 ccl_merge     per pixel: union-find (atomicMin) links to the row above (8-connectivity)
-//   3 ccl_compress  label = root = smallest linear index of the component (canonical)
-//   4 root_count / root_scan / root_assign : roots in raster order -> component id k < max_boxes
-//   5 comp_extent   per run start: atomicMax of the component's bottom row (the top row is the root's row)
-//   6 seg_scan      per page: row-extreme segments; 7 row_extremes: per-row min/max x (atomics)
-//   8 comp_box      one wave per component: hull (monotone chains), rotating calipers over hull
+// Pipeline (all stream-ordered kernels, no host round trip).  Steps 1-7 work on the RUNS of the binarised map, one wave per page row:
+//   1 rl_mask / row_scan / rl_fill   threshold -> 64-bit masks per row segment -> run list [xs, xe] of the page in raster order
+//   2 rl_merge      union-find (atomicMin) over run ids: a run joins the runs of the row above it touches (8-connectivity)
+//   3 rl_roots      parent = root = the component's first run (starts at its smallest linear pixel index: canonical); roots per row
+//   4 row_scan / rl_assign : roots in raster order -> component id k < max_boxes, top row
+//   5 rl_extent     atomicMax of the component's bottom row
+//   6 seg_scan / seg_init   per page: row-extreme segments; 7 rl_extremes: per-row min/max x (atomics, one pair per run)
+//   8 comp_box      one work-group per component: hull (monotone chains), rotating calipers over hull
 //                   edges (lanes = edges), fixed-point score (lanes = pixels), unclip, corner order
 //   9 compact       valid boxes in component order -> boxes / scores / count
 #include "dbpost.h"
@@ -34,13 +34,23 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
     }
 }
 
-// ---- 1: one wave per (page,row), four rows per workgroup; the row's probabilities are requested 8 chunks at a time ----
-__global__ __launch_bounds__(256) void ccl_init_kernel(const bf16_t* prob, int* label, int Hp, int Wp, int vh, int vw, float thresh, int rows_total) {
-    const int wrow = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (wrow >= rows_total) return;
+// ---- 1-7: connected components over RUNS.  A row of the binarised map is a short list of runs (a text page: ~10 per row, 2 %
+// of what a per-pixel label image holds), in raster order; everything between the threshold and the per-component row extremes
+// works on that list.  All kernels are one wave per (page, row), four rows per work-group.
+#define ROW_WAVE_DECODE                                                        \
+    const int wrow = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63; \
+    if (wrow >= rows_total) return;                                            \
     const int row = wrow % Hp, pg = wrow / Hp;
+
+// 1a: threshold -> one 64-bit mask per 64-pixel segment of the row + the number of runs in the row; the row's probabilities are
+// requested 8 segments at a time
+__global__ __launch_bounds__(256) void rl_mask_kernel(const bf16_t* prob, unsigned long long* mask, int* runcnt, int Hp, int Wp, int nseg, int vh, int vw,
+                                                      float thresh, int rows_total) {
+    ROW_WAVE_DECODE
     const size_t base = ((size_t)pg * Hp + row) * Wp;
-    int carry = -1;  // run start (x) continuing from the previous chunk, -1 = none
+    unsigned long long* mrow = mask + ((size_t)pg * Hp + row) * nseg;
+    int cnt = 0;
+    unsigned long long carry = 0;   // bit 63 of the previous segment
     for (int xb = 0; xb < Wp; xb += 64 * 8) {
         float pv[8];
 #pragma unroll
@@ -52,85 +62,18 @@ __global__ __launch_bounds__(256) void ccl_init_kernel(const bf16_t* prob, int* 
         for (int u = 0; u < 8; ++u) {
             const int x0 = xb + u * 64, x = x0 + lane;
             if (x0 >= Wp) break;
-            const bool fg = x < vw && row < vh && pv[u] > thresh;
-            const unsigned long long m = __ballot(fg);
-            const unsigned long long below = (~m) & ((1ull << lane) - 1ull);  // background lanes below me
-            int start;
-            if (below) start = x0 + (63 - __clzll(below)) + 1;
-            else start = carry >= 0 ? carry : x0;
-            if (x < Wp) label[base + x] = fg ? (int)(row * Wp + start) : -1;
-            // carry for next chunk: if lane 63 is fg, its run start
-            const int s63 = __shfl(start, 63);
-            carry = (m >> 63) ? s63 : -1;
+            const unsigned long long m = __ballot(x < vw && row < vh && pv[u] > thresh);
+            if (lane == 0) mrow[x0 >> 6] = m;
+            cnt += __popcll(m & ~((m << 1) | carry));
+            carry = m >> 63;
         }
     }
+    if (lane == 0) runcnt[(size_t)pg * (Hp + 1) + row] = cnt;
 }
-
-// Per-pixel passes 2, 3, 5, 7: grid (chunks of 1024 pixels, pages); one thread = 4 consecutive pixels of a row (Wp % 4 == 0), so
-// the label image moves as 16-byte vectors, the index arithmetic is 32-bit and the (few) foreground quads do the real work.
-#define PIX4_DECODE                                                   \
-    const int per = Hp * Wp, pg = blockIdx.y;                         \
-    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;               \
-    if (i >= per) return;
-
-// ---- 2 ----
-__global__ __launch_bounds__(256) void ccl_merge_kernel(int* label, int Hp, int Wp, int vh, int vw) {
-    PIX4_DECODE
-    int* L = label + (size_t)pg * per;
-    const int4 cv = *reinterpret_cast<const int4*>(L + i);
-    if ((cv.x & cv.y & cv.z & cv.w) < 0) return;  // four background pixels
-    const int y = i / Wp, x0 = i - y * Wp;
-    if (y == 0 || y >= vh) return;
-    // signs of the 6 labels above and of the one to the left (signs never change while roots are being merged)
-    const int4 uv = *reinterpret_cast<const int4*>(L + i - Wp);
-    const int ul = x0 > 0 ? L[i - Wp - 1] : -1, ur = x0 + 4 < Wp ? L[i - Wp + 4] : -1, wl = x0 > 0 ? L[i - 1] : -1;
-    const int cur[4] = {cv.x, cv.y, cv.z, cv.w};
-    const int up[6] = {ul, uv.x, uv.y, uv.z, uv.w, ur};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int x = x0 + e;
-        if (x >= vw || cur[e] < 0) continue;
-        const bool n = up[e + 1] >= 0;
-        const bool w = x > 0 && (e ? cur[e - 1] : wl) >= 0;
-        const bool nw = x > 0 && up[e] >= 0;
-        const bool ne = x + 1 < vw && up[e + 2] >= 0;
-        if (n) { if (!(w && nw)) uf_union(L, i + e, i + e - Wp); }
-        else {
-            if (ne) uf_union(L, i + e, i + e - Wp + 1);
-            if (nw && !w) uf_union(L, i + e, i + e - Wp - 1);
-        }
-    }
-}
-
-// ---- 3 ----
-__global__ __launch_bounds__(256) void ccl_compress_kernel(int* label, int Hp, int Wp) {
-    PIX4_DECODE
-    int* L = label + (size_t)pg * per;
-    int4 v = *reinterpret_cast<const int4*>(L + i);
-    if ((v.x & v.y & v.z & v.w) < 0) return;
-    if (v.x >= 0) v.x = uf_find(L, v.x);
-    if (v.y >= 0) v.y = uf_find(L, v.y);
-    if (v.z >= 0) v.z = uf_find(L, v.z);
-    if (v.w >= 0) v.w = uf_find(L, v.w);
-    *reinterpret_cast<int4*>(L + i) = v;
-}
-
-// ---- 4a: roots per row ----
-__global__ __launch_bounds__(64) void root_count_kernel(const int* label, int* rowcnt, int Hp, int Wp) {
-    const int row = blockIdx.x % Hp, pg = blockIdx.x / Hp, lane = threadIdx.x;
-    const size_t base = ((size_t)pg * Hp + row) * Wp;
-    int cnt = 0;
-    for (int x0 = 0; x0 < Wp; x0 += 64) {
-        const int x = x0 + lane;
-        const bool root = x < Wp && label[base + x] == row * Wp + x;
-        cnt += __popcll(__ballot(root));
-    }
-    if (lane == 0) rowcnt[(size_t)pg * Hp + row] = cnt;
-}
-// ---- 4b: exclusive scan per page (one wave, chunked) ----
-__global__ __launch_bounds__(64) void root_scan_kernel(int* rowcnt, int* ncomp, int Hp) {
+// exclusive scan of a page's Hp row counts (one wave, chunked): cnt[r] -> offset of row r, cnt[Hp] = total (also -> total_out)
+__global__ __launch_bounds__(64) void row_scan_kernel(int* cnt, int* total_out, int Hp) {
     const int pg = blockIdx.x, lane = threadIdx.x;
-    int* rc = rowcnt + (size_t)pg * Hp;
+    int* rc = cnt + (size_t)pg * (Hp + 1);
     int run = 0;
     for (int r0 = 0; r0 < Hp; r0 += 64) {
         const int r = r0 + lane;
@@ -141,47 +84,109 @@ __global__ __launch_bounds__(64) void root_scan_kernel(int* rowcnt, int* ncomp, 
         if (r < Hp) rc[r] = run + inc - v;
         run += __shfl(inc, 63);
     }
-    if (lane == 0) ncomp[pg] = run;
+    if (lane == 0) { rc[Hp] = run; if (total_out) total_out[pg] = run; }
 }
-// ---- 4c: ordered ids; cid[root pixel] = k (or -1 beyond the cap); per-component init ----
-__global__ __launch_bounds__(64) void root_assign_kernel(const int* label, const int* rowoff, int* cid, int* comp_root, int* ymin, int* ymax,
-                                                          int Hp, int Wp, int maxc) {
-    const int row = blockIdx.x % Hp, pg = blockIdx.x / Hp, lane = threadIdx.x;
-    const size_t base = ((size_t)pg * Hp + row) * Wp;
-    int k0 = rowoff[(size_t)pg * Hp + row];
-    for (int x0 = 0; x0 < Wp; x0 += 64) {
-        const int x = x0 + lane;
-        const bool root = x < Wp && label[base + x] == row * Wp + x;
+// 1b: masks -> runs [xs, xe] of the row at its offset in the page's run list; a run is its own union-find parent.  Lanes = segments:
+// the j-th run start of the row pairs with the j-th run end (a run may span segments), so starts and ends are ranked separately.
+__global__ __launch_bounds__(256) void rl_fill_kernel(const unsigned long long* mask, const int* runoff, unsigned short* rxs, unsigned short* rxe, int* parent,
+                                                      int Hp, int nseg, size_t runcap, int rows_total) {
+    ROW_WAVE_DECODE
+    const unsigned long long* mrow = mask + ((size_t)pg * Hp + row) * nseg;
+    const size_t rb = (size_t)pg * runcap;
+    int sbase = runoff[(size_t)pg * (Hp + 1) + row], ebase = sbase;
+    unsigned long long carry = 0;
+    for (int s0 = 0; s0 < nseg; s0 += 64) {
+        const int sg = s0 + lane;
+        const unsigned long long m = sg < nseg ? mrow[sg] : 0ull;
+        unsigned long long prev = (unsigned long long)__shfl_up((int)(m >> 63), 1);          // bit 63 of the segment to the left
+        if (lane == 0) prev = carry;
+        unsigned long long next = (unsigned long long)(__shfl_down((int)(m & 1ull), 1) & 1);  // bit 0 of the segment to the right
+        if (lane == 63) next = s0 + 64 < nseg ? (mrow[s0 + 64] & 1ull) : 0ull;
+        unsigned long long st = m & ~((m << 1) | prev), en = m & ~((m >> 1) | (next << 63));
+        int si = __popcll(st), ei = __popcll(en);
+        const int ns = si, ne = ei;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int a = __shfl_up(si, d), b = __shfl_up(ei, d);
+            if (lane >= d) { si += a; ei += b; }
+        }
+        int sp = sbase + si - ns, ep = ebase + ei - ne;   // exclusive ranks
+        while (st) { const int bit = __ffsll((long long)st) - 1; st &= st - 1; rxs[rb + sp] = (unsigned short)(sg * 64 + bit); parent[rb + sp] = sp; ++sp; }
+        while (en) { const int bit = __ffsll((long long)en) - 1; en &= en - 1; rxe[rb + ep] = (unsigned short)(sg * 64 + bit); ++ep; }
+        sbase += __shfl(si, 63); ebase += __shfl(ei, 63);
+        carry = (unsigned long long)__shfl((int)(m >> 63), 63);
+    }
+}
+// 2: a run joins every run of the row above that it touches (8-connectivity: [xs - 1, xe + 1] overlaps [xs', xe']).  Run ids grow in
+// raster order and the union keeps the smaller root, so a component's root is its first run — the one that starts at the
+// component's smallest linear pixel index, the canonical root of the per-pixel definition.
+__global__ __launch_bounds__(256) void rl_merge_kernel(const int* runoff, const unsigned short* rxs, const unsigned short* rxe, int* parent, int Hp,
+                                                       size_t runcap, int rows_total) {
+    ROW_WAVE_DECODE
+    if (row == 0) return;
+    const int* ro = runoff + (size_t)pg * (Hp + 1);
+    const int u0 = ro[row - 1], r0 = ro[row], r1 = ro[row + 1];
+    if (u0 == r0) return;
+    const size_t rb = (size_t)pg * runcap;
+    int* P = parent + rb;
+    for (int id = r0 + lane; id < r1; id += 64) {
+        const int xs = rxs[rb + id], xe = rxe[rb + id];
+        int lo = u0, hi = r0;   // first run of the row above with xe' + 1 >= xs
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)rxe[rb + mid] + 1 < xs) lo = mid + 1; else hi = mid; }
+        for (int t = lo; t < r0 && (int)rxs[rb + t] <= xe + 1; ++t) uf_union(P, id, t);
+    }
+}
+// 3 + 4a: every run learns its root; roots per row are counted
+__global__ __launch_bounds__(256) void rl_roots_kernel(const int* runoff, int* parent, int* rootcnt, int Hp, size_t runcap, int rows_total) {
+    ROW_WAVE_DECODE
+    const int* ro = runoff + (size_t)pg * (Hp + 1);
+    const int r0 = ro[row], r1 = ro[row + 1];
+    int* P = parent + (size_t)pg * runcap;
+    int cnt = 0;
+    for (int i0 = r0; i0 < r1; i0 += 64) {   // (wave-uniform bounds: the ballot sees every lane)
+        const int id = i0 + lane;
+        bool root = false;
+        if (id < r1) {
+            const int p = P[id];
+            root = p == id;
+            if (!root) P[id] = uf_find(P, p);   // concurrent compressions only ever replace a parent by an ancestor
+        }
+        cnt += __popcll(__ballot(root));
+    }
+    if (lane == 0) rootcnt[(size_t)pg * (Hp + 1) + row] = cnt;
+}
+// 4c: roots in raster order -> component id k (or -1 beyond the cap); the root's row IS the component's top row
+__global__ __launch_bounds__(256) void rl_assign_kernel(const int* runoff, const int* rootoff, const int* parent, int* cidr, int* ymin, int* ymax, int Hp,
+                                                        size_t runcap, int maxc, int rows_total) {
+    ROW_WAVE_DECODE
+    const int* ro = runoff + (size_t)pg * (Hp + 1);
+    const int r0 = ro[row], r1 = ro[row + 1];
+    const size_t rb = (size_t)pg * runcap;
+    int k0 = rootoff[(size_t)pg * (Hp + 1) + row];
+    for (int i0 = r0; i0 < r1; i0 += 64) {
+        const int id = i0 + lane;
+        const bool root = id < r1 && parent[rb + id] == id;
         const unsigned long long m = __ballot(root);
         if (root) {
             const int k = k0 + __popcll(m & ((1ull << lane) - 1ull));
-            if (k < maxc) {
-                cid[base + x] = k;
-                comp_root[(size_t)pg * maxc + k] = row * Wp + x;
-                ymin[(size_t)pg * maxc + k] = row;  // the root is the smallest linear index of its component: its row IS the top row
-                ymax[(size_t)pg * maxc + k] = row;
-            } else cid[base + x] = -1;
+            cidr[rb + id] = k < maxc ? k : -1;
+            if (k < maxc) { ymin[(size_t)pg * maxc + k] = row; ymax[(size_t)pg * maxc + k] = row; }
         }
         k0 += __popcll(m);
     }
 }
-// ---- 5 ----
-__global__ __launch_bounds__(256) void comp_extent_kernel(const int* label, const int* cid, int* ymax, int Hp, int Wp, int maxc) {
-    PIX4_DECODE
-    const int* L = label + (size_t)pg * per;
-    const int4 v = *reinterpret_cast<const int4*>(L + i);
-    if ((v.x & v.y & v.z & v.w) < 0) return;
-    const int y = i / Wp, x0 = i - y * Wp;
-    const int cur[5] = {x0 > 0 ? L[i - 1] : -1, v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (cur[e + 1] < 0 || cur[e] >= 0) continue;  // only run starts contribute (one atomic per run)
-        const int k = cid[(size_t)pg * per + cur[e + 1]];
-        if (k < 0) continue;
-        atomicMax(&ymax[(size_t)pg * maxc + k], y);  // (a plain read as pre-check measured 2x slower: it queues behind the line's atomics)
+// 5: bottom row of every component
+__global__ __launch_bounds__(256) void rl_extent_kernel(const int* runoff, const int* parent, const int* cidr, int* ymax, int Hp, size_t runcap, int maxc,
+                                                        int rows_total) {
+    ROW_WAVE_DECODE
+    const int* ro = runoff + (size_t)pg * (Hp + 1);
+    const size_t rb = (size_t)pg * runcap;
+    for (int id = ro[row] + lane; id < ro[row + 1]; id += 64) {
+        const int k = cidr[rb + parent[rb + id]];
+        if (k >= 0) atomicMax(&ymax[(size_t)pg * maxc + k], row);
     }
 }
-// ---- 6: per page segment offsets (one wave) + init of the segments ----
+// ---- 6: per page segment offsets (one wave) + init of the segments in use ----
 __global__ __launch_bounds__(64) void seg_scan_kernel(const int* ncomp, const int* ymin, const int* ymax, int* segoff, int maxc) {
     const int pg = blockIdx.x, lane = threadIdx.x;
     const int n = ncomp[pg] < maxc ? ncomp[pg] : maxc;
@@ -197,32 +202,25 @@ __global__ __launch_bounds__(64) void seg_scan_kernel(const int* ncomp, const in
     }
     if (lane == 0) segoff[(size_t)pg * (maxc + 1) + n] = run;
 }
-__global__ void seg_init_kernel(int* rowmin, int* rowmax, size_t total) {
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-        rowmin[g] = 0x7fffffff; rowmax[g] = -1;
-    }
+__global__ __launch_bounds__(256) void seg_init_kernel(const int* ncomp, const int* segoff, int* rowmin, int* rowmax, int maxc, size_t seg_cap) {
+    const int pg = blockIdx.y;
+    const int n = ncomp[pg] < maxc ? ncomp[pg] : maxc;
+    const int total = segoff[(size_t)pg * (maxc + 1) + n];
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < total; g += gridDim.x * 256) { rowmin[(size_t)pg * seg_cap + g] = 0x7fffffff; rowmax[(size_t)pg * seg_cap + g] = -1; }
 }
-// ---- 7 ----
-__global__ __launch_bounds__(256) void row_extremes_kernel(const int* label, const int* cid, const int* ymin, const int* segoff, int* rowmin, int* rowmax,
-                                                           int Hp, int Wp, int vw, int maxc, size_t seg_cap) {
-    PIX4_DECODE
-    const int* L = label + (size_t)pg * per;
-    const int4 v = *reinterpret_cast<const int4*>(L + i);
-    if ((v.x & v.y & v.z & v.w) < 0) return;
-    const int y = i / Wp, x0 = i - y * Wp;
-    const int cur[6] = {x0 > 0 ? L[i - 1] : -1, v.x, v.y, v.z, v.w, x0 + 4 < Wp ? L[i + 4] : -1};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int r = cur[e + 1], x = x0 + e;
-        if (r < 0) continue;
-        const bool start = !(x > 0 && cur[e] >= 0);
-        const bool end = !(x + 1 < vw && cur[e + 2] >= 0);
-        if (!start && !end) continue;
-        const int k = cid[(size_t)pg * per + r];
+// ---- 7: leftmost / rightmost foreground pixel of every component in every row it covers ----
+__global__ __launch_bounds__(256) void rl_extremes_kernel(const int* runoff, const unsigned short* rxs, const unsigned short* rxe, const int* parent,
+                                                          const int* cidr, const int* ymin, const int* segoff, int* rowmin, int* rowmax, int Hp,
+                                                          size_t runcap, int maxc, size_t seg_cap, int rows_total) {
+    ROW_WAVE_DECODE
+    const int* ro = runoff + (size_t)pg * (Hp + 1);
+    const size_t rb = (size_t)pg * runcap;
+    for (int id = ro[row] + lane; id < ro[row + 1]; id += 64) {
+        const int k = cidr[rb + parent[rb + id]];
         if (k < 0) continue;
-        const size_t sg = (size_t)pg * seg_cap + segoff[(size_t)pg * (maxc + 1) + k] + (y - ymin[(size_t)pg * maxc + k]);
-        if (start) atomicMin(&rowmin[sg], x);
-        if (end) atomicMax(&rowmax[sg], x);
+        const size_t sg = (size_t)pg * seg_cap + segoff[(size_t)pg * (maxc + 1) + k] + (row - ymin[(size_t)pg * maxc + k]);
+        atomicMin(&rowmin[sg], (int)rxs[rb + id]);
+        atomicMax(&rowmax[sg], (int)rxe[rb + id]);
     }
 }
 
@@ -530,38 +528,45 @@ __global__ __launch_bounds__(256) void rec_crop_kernel(const uint8_t* pages, int
     }
 }
 
-inline int grid_for(size_t total) {
-    size_t g = (total + 255) / 256;
-    return (int)(g > 256 * 32 ? 256 * 32 : (g ? g : 1));
-}
-
 }  // namespace
 
+// worst case of a row: every other pixel starts a run
+static size_t dbpost_runcap(int Hp, int Wp) { return (size_t)Hp * ((Wp + 1) / 2); }
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
 size_t dbpost_workspace_bytes(int B, int Hp, int Wp, int maxc) {
-    const size_t per = (size_t)Hp * Wp;
     const size_t seg_cap = (size_t)maxc * Hp;  // worst case: every candidate spans the page height
+    const size_t runcap = dbpost_runcap(Hp, Wp), nseg = (Wp + 63) / 64;
     size_t n = 0;
-    n += per * B * 4 * 2;                       // label, cid
-    n += (size_t)B * Hp * 4 + 256;              // rowcnt
-    n += (size_t)B * 4 + 256;                   // ncomp
-    n += (size_t)B * maxc * 4 * 3 + 768;        // comp_root, ymin, ymax
-    n += (size_t)B * (maxc + 1) * 4 + 256;      // segoff
-    n += (size_t)B * seg_cap * 4 * 2 + 512;     // rowmin, rowmax
-    n += (size_t)B * seg_cap * 2 * 8 + 256;     // hull
-    n += (size_t)B * maxc * (8 * 4 + 4 + 4) + 768;
+    n += al256((size_t)B * Hp * nseg * 8);             // masks
+    n += 2 * al256((size_t)B * (Hp + 1) * 4);          // run / root counts -> offsets
+    n += 2 * al256((size_t)B * 4);                     // nruns, ncomp
+    n += 2 * al256((size_t)B * runcap * 2);            // run xs, xe
+    n += 2 * al256((size_t)B * runcap * 4);            // parent, component id of root runs
+    n += 2 * al256((size_t)B * maxc * 4);              // ymin, ymax
+    n += al256((size_t)B * (maxc + 1) * 4);            // segoff
+    n += 2 * al256((size_t)B * seg_cap * 4);           // rowmin, rowmax
+    n += al256((size_t)B * seg_cap * 2 * 8);           // hull
+    n += al256((size_t)B * maxc * 8 * 4) + 2 * al256((size_t)B * maxc * 4);
     return n + 4096;
 }
 
 hipError_t dbpost_launch(const DbPostParams& p, void* workspace, hipStream_t st) {
     const int B = p.B, Hp = p.Hp, Wp = p.Wp, maxc = p.max_boxes;
-    const size_t per = (size_t)Hp * Wp, seg_cap = (size_t)maxc * Hp;
+    if (B <= 0 || Hp <= 0 || Wp <= 0 || Wp > 65535 || maxc <= 0 || (size_t)B * Hp >= (1ull << 31) || dbpost_runcap(Hp, Wp) >= (1ull << 31)) return hipErrorInvalidValue;
+    const size_t seg_cap = (size_t)maxc * Hp, runcap = dbpost_runcap(Hp, Wp);
+    const int nseg = (Wp + 63) / 64;
     uint8_t* w = static_cast<uint8_t*>(workspace);
-    auto take = [&](size_t bytes) { void* r = w; w += (bytes + 255) & ~(size_t)255; return r; };
-    int* label = static_cast<int*>(take(per * B * 4));
-    int* cid = static_cast<int*>(take(per * B * 4));
-    int* rowcnt = static_cast<int*>(take((size_t)B * Hp * 4));
+    auto take = [&](size_t bytes) { void* r = w; w += al256(bytes); return r; };
+    unsigned long long* mask = static_cast<unsigned long long*>(take((size_t)B * Hp * nseg * 8));
+    int* runoff = static_cast<int*>(take((size_t)B * (Hp + 1) * 4));
+    int* rootoff = static_cast<int*>(take((size_t)B * (Hp + 1) * 4));
+    int* nruns = static_cast<int*>(take((size_t)B * 4));
     int* ncomp = static_cast<int*>(take((size_t)B * 4));
-    int* comp_root = static_cast<int*>(take((size_t)B * maxc * 4));
+    unsigned short* rxs = static_cast<unsigned short*>(take((size_t)B * runcap * 2));
+    unsigned short* rxe = static_cast<unsigned short*>(take((size_t)B * runcap * 2));
+    int* parent = static_cast<int*>(take((size_t)B * runcap * 4));
+    int* cidr = static_cast<int*>(take((size_t)B * runcap * 4));
     int* ymin = static_cast<int*>(take((size_t)B * maxc * 4));
     int* ymax = static_cast<int*>(take((size_t)B * maxc * 4));
     int* segoff = static_cast<int*>(take((size_t)B * (maxc + 1) * 4));
@@ -572,18 +577,19 @@ hipError_t dbpost_launch(const DbPostParams& p, void* workspace, hipStream_t st)
     float* score_tmp = static_cast<float*>(take((size_t)B * maxc * 4));
     int* valid_tmp = static_cast<int*>(take((size_t)B * maxc * 4));
 
-    if (Wp % 4 != 0 || per > 0x7fffffffull / 4) return hipErrorInvalidValue;
-    const dim3 gpix4((unsigned)((per / 4 + 255) / 256), (unsigned)B);
-    hipLaunchKernelGGL(ccl_init_kernel, dim3((B * Hp + 3) / 4), dim3(256), 0, st, p.prob, label, Hp, Wp, p.valid_h, p.valid_w, p.thresh, B * Hp);
-    hipLaunchKernelGGL(ccl_merge_kernel, gpix4, dim3(256), 0, st, label, Hp, Wp, p.valid_h, p.valid_w);
-    hipLaunchKernelGGL(ccl_compress_kernel, gpix4, dim3(256), 0, st, label, Hp, Wp);
-    hipLaunchKernelGGL(root_count_kernel, dim3(B * Hp), dim3(64), 0, st, label, rowcnt, Hp, Wp);
-    hipLaunchKernelGGL(root_scan_kernel, dim3(B), dim3(64), 0, st, rowcnt, ncomp, Hp);
-    hipLaunchKernelGGL(root_assign_kernel, dim3(B * Hp), dim3(64), 0, st, label, rowcnt, cid, comp_root, ymin, ymax, Hp, Wp, maxc);
-    hipLaunchKernelGGL(comp_extent_kernel, gpix4, dim3(256), 0, st, label, cid, ymax, Hp, Wp, maxc);
+    const int rows = B * Hp;
+    const dim3 grows((unsigned)((rows + 3) / 4));
+    hipLaunchKernelGGL(rl_mask_kernel, grows, dim3(256), 0, st, p.prob, mask, runoff, Hp, Wp, nseg, p.valid_h, p.valid_w, p.thresh, rows);
+    hipLaunchKernelGGL(row_scan_kernel, dim3(B), dim3(64), 0, st, runoff, nruns, Hp);
+    hipLaunchKernelGGL(rl_fill_kernel, grows, dim3(256), 0, st, mask, runoff, rxs, rxe, parent, Hp, nseg, runcap, rows);
+    hipLaunchKernelGGL(rl_merge_kernel, grows, dim3(256), 0, st, runoff, rxs, rxe, parent, Hp, runcap, rows);
+    hipLaunchKernelGGL(rl_roots_kernel, grows, dim3(256), 0, st, runoff, parent, rootoff, Hp, runcap, rows);
+    hipLaunchKernelGGL(row_scan_kernel, dim3(B), dim3(64), 0, st, rootoff, ncomp, Hp);
+    hipLaunchKernelGGL(rl_assign_kernel, grows, dim3(256), 0, st, runoff, rootoff, parent, cidr, ymin, ymax, Hp, runcap, maxc, rows);
+    hipLaunchKernelGGL(rl_extent_kernel, grows, dim3(256), 0, st, runoff, parent, cidr, ymax, Hp, runcap, maxc, rows);
     hipLaunchKernelGGL(seg_scan_kernel, dim3(B), dim3(64), 0, st, ncomp, ymin, ymax, segoff, maxc);
-    hipLaunchKernelGGL(seg_init_kernel, dim3(grid_for((size_t)B * seg_cap)), dim3(256), 0, st, rowmin, rowmax, (size_t)B * seg_cap);
-    hipLaunchKernelGGL(row_extremes_kernel, gpix4, dim3(256), 0, st, label, cid, ymin, segoff, rowmin, rowmax, Hp, Wp, p.valid_w, maxc, seg_cap);
+    hipLaunchKernelGGL(seg_init_kernel, dim3(64, B), dim3(256), 0, st, ncomp, segoff, rowmin, rowmax, maxc, seg_cap);
+    hipLaunchKernelGGL(rl_extremes_kernel, grows, dim3(256), 0, st, runoff, rxs, rxe, parent, cidr, ymin, segoff, rowmin, rowmax, Hp, runcap, maxc, seg_cap, rows);
     hipLaunchKernelGGL(comp_box_kernel, dim3(B * maxc), dim3(256), 0, st, p.prob, ncomp, ymin, ymax, segoff, rowmin, rowmax, hull, box_tmp,
                        score_tmp, valid_tmp, Hp, Wp, p.valid_h, p.valid_w, maxc, seg_cap, p.box_thresh, p.unclip_ratio, p.min_size);
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(64), 0, st, box_tmp, score_tmp, valid_tmp, p.boxes, p.scores, p.counts, maxc);
