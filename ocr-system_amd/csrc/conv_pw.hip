@@ -72,10 +72,15 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvParams p, con
 
     // weight fragments of one 64-channel group: [kstep][nt]
     bf16x8_t afr[KSTEPS][2];
-#define LOAD_W(q_)                                                                                                          \
-    _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks)                                                                  \
+#define LOAD_W_RANGE(q_, ks0_, ks1_)                                                                                        \
+    _Pragma("unroll") for (int ks = (ks0_); ks < (ks1_); ++ks)                                                             \
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                   \
             afr[ks][nt] = *reinterpret_cast<const bf16x8_t*>(p.wpk + ((((size_t)(q_) * nchunks + (ks >> 1)) * 4 + 2 * (ks & 1) + h) * 64 + nt * 32 + r) * 8);
+#define LOAD_W(q_) LOAD_W_RANGE(q_, 0, KSTEPS)
+    // Cin = 128: a whole group of fragments (64 registers) next to the accumulators, the bias and the residual of the epilogue does
+    // not fit 256 registers (hipcc spilled 34 of them to scratch inside the MFMA loop): the second half is requested once the
+    // bias / residual registers are dead; the next group's first MFMAs only need the first half
+    constexpr int KS_EARLY = CIN > 64 ? KSTEPS / 2 : KSTEPS;
     LOAD_W(0)
     // fused tail: the 64 -> 4 weights of the last transposed conv are the same for every group and pixel: once per workgroup
     // (inside the loop hipcc cannot hoist them past the stores and re-reads them 32 times per tile)
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvParams p, con
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][nt], bfr[mt], acc[mt][nt], 0, 0, 0);
         }
-        if (q + 1 < ngroups) { LOAD_W(q + 1) }  // next group's weights fly under this group's epilogue
+        if (q + 1 < ngroups) { LOAD_W_RANGE(q + 1, 0, KS_EARLY) }  // next group's weights fly under this group's epilogue
 
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -158,6 +163,12 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvParams p, con
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int j = 0; j < 16; ++j) acc[mt][nt][j] = apply_act(acc[mt][nt][j], p.act);
+        }
+
+        if constexpr (KS_EARLY < KSTEPS) {
+            __builtin_amdgcn_sched_barrier(0);   // (the scheduler would hoist these loads above the adds and bring the pressure back)
+            if (q + 1 < ngroups) { LOAD_W_RANGE(q + 1, KS_EARLY, KSTEPS) }
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         if constexpr (!fused) {
@@ -242,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvParams p, con
         }
     }
 #undef LOAD_W
+#undef LOAD_W_RANGE
 }
 
 template <int CIN, int MODE>

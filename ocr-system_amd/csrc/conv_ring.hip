@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
 #define RING_T(acc_) if constexpr (PROF) { t1 = clock64(); acc_ += t1 - t0; t0 = t1; }
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;   // (wave: a scalar, so that everything derived from it stays in SGPRs)
 
     // logical tile axes: y = the 16-row axis, x = the 32-lane axis; image pixel (ly, lx) sits at pixel offset ly * sy + lx * sx
     const int LH = TR ? p.W : p.H, LW = TR ? p.H : p.W;
@@ -80,27 +80,44 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
 
     // multi-source input: chunk c comes from source c / cps, stored at 1 / 2^shift of the resolution with Cin / n_src channels
     const int nsrc = p.n_src > 1 ? p.n_src : 1, cps = nchunks / nsrc;
-    // halo pieces of this thread (the same for every tile) and their global offsets for the tile / source being requested
+    // (selected with constant indices: indexing the kernel argument with a run-time `src` makes hipcc copy the struct to scratch,
+    // and scratch loads queue with the LDS-DMA on the vector-memory counter)
+    auto src_shift = [&](int src) { return src == 0 ? p.xs_shift[0] : (src == 1 ? p.xs_shift[1] : (src == 2 ? p.xs_shift[2] : p.xs_shift[3])); };
+    auto src_ptr = [&](int src) { return src == 0 ? p.xs[0] : (src == 1 ? p.xs[1] : (src == 2 ? p.xs[2] : p.xs[3])); };
+    // halo pieces of this thread: piece i = tid + 256 * it is slice c of halo pixel (hy, hx) — the same for every tile, so the
+    // divisions are done once and kept packed, two pieces per register (left to itself hipcc hoists the unpacked (hy, hx) of all
+    // ten pieces out of the tile loop, spills them, and reloads them from scratch in the middle of a chunk: a scratch load sits
+    // on the vector-memory counter BEHIND the LDS-DMA requests in flight, i.e. it waits for them to land) ...
+    unsigned a_item[(R_AIT + 1) / 2];
+#pragma unroll
+    for (int it = 0; it < R_AIT; ++it) {
+        const int i = tid + 256 * it, pi = i >> 1, hy = pi / R_HW, hx = pi - hy * R_HW;
+        const unsigned e = (unsigned)hy | ((unsigned)hx << 5) | ((unsigned)(i & 1) << 11) | ((unsigned)(i < R_A_ITEMS) << 12);
+        if (it & 1) a_item[it >> 1] |= e << 16; else a_item[it >> 1] = e;
+    }
+    // ... and their global offsets for the tile / source being requested
     int a_goff[R_AIT];
     auto describe = [&](const RingTile& t, int src) {
-        const int sh = nsrc > 1 ? p.xs_shift[src] : 0, cin_s = nsrc > 1 ? 16 * cps : p.Cin, ws = p.W >> sh;
+        const int sh = nsrc > 1 ? src_shift(src) : 0, cin_s = nsrc > 1 ? 16 * cps : p.Cin, ws = p.W >> sh;
+#pragma unroll
+        for (int j = 0; j < (R_AIT + 1) / 2; ++j) asm volatile("" : "+v"(a_item[j]));   // opaque: the unpacking below stays inside the tile loop
 #pragma unroll
         for (int it = 0; it < R_AIT; ++it) {
-            const int i = tid + 256 * it, pi = i >> 1, c = i & 1;
-            const int hy = pi / R_HW, hx = pi - hy * R_HW;
+            const unsigned e = (a_item[it >> 1] >> (16 * (it & 1))) & 0xffffu;
+            const int hy = e & 31, hx = (e >> 5) & 63, c = (e >> 11) & 1;
             const int ly = t.oyb - 1 + hy, lx = t.oxb - 1 + hx;
-            const bool inb = i < R_A_ITEMS && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
+            const bool inb = (e >> 12) != 0 && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
             const int cs = c ^ ((hx >> 3) & 1);   // LDS slot c of this pixel holds slice cs (bank swizzle, see the fragment reads)
             const int iy = TR ? lx : ly, ix = TR ? ly : lx;   // image row / column of the halo pixel
             const int pix = nsrc > 1 ? (iy >> sh) * ws + (ix >> sh) : ly * sy + lx * sx;   // nearest-upsampled read of a low-resolution source
             a_goff[it] = inb ? pix * (p.x_blk ? 16 : cin_s) + cs * 8 : -1;
-            if (PROF && (p.dbg_skip & 8)) a_goff[it] = i * 8;   // timing experiment: a perfectly coalesced halo (wrong values)
+            if (PROF && (p.dbg_skip & 8)) a_goff[it] = (tid + 256 * it) * 8;   // timing experiment: a perfectly coalesced halo (wrong values)
         }
     };
     const bf16_t* ximg;
     const bf16_t* wbase;
     auto rebase = [&](const RingTile& t, int src) {
-        if (nsrc > 1) { const int sh = p.xs_shift[src]; ximg = p.xs[src] + (size_t)t.n_img * (p.H >> sh) * (p.W >> sh) * (16 * cps); }
+        if (nsrc > 1) { const int sh = src_shift(src); ximg = src_ptr(src) + (size_t)t.n_img * (p.H >> sh) * (p.W >> sh) * (16 * cps); }
         else ximg = p.x + (size_t)t.n_img * p.H * p.W * p.Cin;
         wbase = p.wpk + (size_t)t.ntile * nchunks * (R_W_ITEMS * 8);
     };
@@ -109,18 +126,17 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
     // Halo pieces outside the image (and the padding pieces of the last round) read a block of zeros; the source is selected
     // arithmetically so that the instruction sits in straight-line code and can be scheduled between the MFMAs.
     auto dma_a = [&](int it, const bf16_t* xa, int tgt) {
-        const int i = tid + 256 * it;
         const unsigned long long in_addr = (unsigned long long)xa + 2ull * (unsigned)a_goff[it];
         const unsigned long long addr = a_goff[it] >= 0 ? in_addr : (unsigned long long)p.zeros;
         if (!(PROF && (p.dbg_skip & 2)))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
-                (__attribute__((address_space(3))) void*)(smem + tgt + (i - lane) * 16), 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(smem + tgt + (wave * 64 + 256 * it) * 16), 16, 0, 0);
     };
     auto dma_w = [&](int it, const bf16_t* wsrc, int tgt) {
         const int i = tid + 256 * it;
         if ((R_W_ITEMS % 256 == 0 || (it + 1) * 256 <= R_W_ITEMS || wave < (R_W_ITEMS % 256) / 64) && !(PROF && (p.dbg_skip & 1)))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (i ^ ((i >> 4) & 1)) * 8),   // the two slices of a row swapped for rows 8..15 (mod 16)
-                (__attribute__((address_space(3))) void*)(smem + R_A_BYTES + tgt + (i - lane) * 16), 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(smem + R_A_BYTES + tgt + (wave * 64 + 256 * it) * 16), 16, 0, 0);
     };
     static_assert(R_W_ITEMS % 64 == 0, "weight pieces split on wave boundaries");
     // the k-th of the R_AIT + R_WIT requests of a chunk: halo first (it may come from HBM), weights (L2) after
