@@ -243,22 +243,28 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
     RingTile cur{};
     auto epilogue = [&](auto has_res_t, int free_slot) {
         constexpr bool HAS_RES = decltype(has_res_t)::value;
-        const float* bsrc = sBias + cur.ntile * R_BN + 4 * h;
+        int hb = h;
+        asm volatile("" : "+v"(hb));   // opaque copy: the bias address is formed here, not kept in a register across the chunk loop (it was the one spill,
+                                       // and its scratch reload waited for every LDS-DMA request in flight)
+        const float* bsrc = sBias + cur.ntile * R_BN + 4 * hb;
         const int rpix_stride = p.res_blk ? 16 : p.res_cstride, rblk_stride = p.res_blk ? hw * 16 : 16;   // as for the output
-        const bf16_t* rimg = HAS_RES ? p.res + (size_t)cur.n_img * hw * p.res_cstride + (p.res_blk ? cur.ntile * (R_BN / 16) * (hw * 16) : cur.ntile * R_BN) + 4 * h : nullptr;
+        const bf16_t* rimg = HAS_RES ? p.res + (size_t)cur.n_img * hw * p.res_cstride + (p.res_blk ? cur.ntile * (R_BN / 16) * (hw * 16) : cur.ntile * R_BN) + 8 * h : nullptr;
         const int ox = cur.oxb + r;
-        uint2 rr[R_MT][R_NT][4];
-        auto load_res = [&](int set, int mt) {
+        // The residual is read the way the output is written: 16 bytes = 8 consecutive channels per lane (16 requests of 1 KB per
+        // tile; as 8-byte pieces in accumulator layout it took 32, every 128-byte line was touched by 8 of them and the 64 KB
+        // tile thrashed the 32 KB L1).  v_permlane32_swap — its own inverse — turns a piece into the two accumulator quads.
+        uint4 rr[R_MT][R_NT][2];
+        auto load_res = [&](int mt) {
             const int oy = cur.oyb + wave * R_MT + mt;
             const bf16_t* rpix = rimg + ((oy < LH && ox < LW) ? oy * sy + ox * sx : 0) * rpix_stride;
 #pragma unroll
             for (int nt = 0; nt < R_NT; ++nt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) rr[set][nt][g] = *reinterpret_cast<const uint2*>(rpix + (nt * 2 + (g >> 1)) * rblk_stride + 8 * (g & 1));
+                for (int gp = 0; gp < 2; ++gp) rr[mt][nt][gp] = *reinterpret_cast<const uint4*>(rpix + (nt * 2 + gp) * rblk_stride);
         };
         if constexpr (HAS_RES) {   // every row requested before the first is used: one exposed memory latency per tile, not one per row
 #pragma unroll
-            for (int mt = 0; mt < R_MT; ++mt) load_res(mt, mt);
+            for (int mt = 0; mt < R_MT; ++mt) load_res(mt);
         }
 #pragma unroll
         for (int mt = 0; mt < R_MT; ++mt) {
@@ -268,15 +274,30 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 b4 = *reinterpret_cast<const float4*>(bsrc + nt * 32 + 8 * g);
-                    float v0 = acc[mt][nt][4 * g + 0] + b4.x, v1 = acc[mt][nt][4 * g + 1] + b4.y;
-                    float v2 = acc[mt][nt][4 * g + 2] + b4.z, v3 = acc[mt][nt][4 * g + 3] + b4.w;
+                    acc[mt][nt][4 * g + 0] += b4.x; acc[mt][nt][4 * g + 1] += b4.y; acc[mt][nt][4 * g + 2] += b4.z; acc[mt][nt][4 * g + 3] += b4.w;
+                }
+#pragma unroll
+            for (int nt = 0; nt < R_NT; ++nt)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    uint32_t rq[2][2] = {{0u, 0u}, {0u, 0u}};   // [quad g0 / g1][channel pair]
                     if constexpr (HAS_RES) {
-                        const uint2 rv = rr[mt][nt][g];
-                        v0 += __uint_as_float(rv.x << 16); v1 += __uint_as_float(rv.x & 0xFFFF0000u);
-                        v2 += __uint_as_float(rv.y << 16); v3 += __uint_as_float(rv.y & 0xFFFF0000u);
+                        const uint4 rv = rr[mt][nt][gp];
+                        const auto sx2 = __builtin_amdgcn_permlane32_swap(rv.x, rv.z, false, false);
+                        const auto sy2 = __builtin_amdgcn_permlane32_swap(rv.y, rv.w, false, false);
+                        rq[0][0] = sx2[0]; rq[0][1] = sy2[0]; rq[1][0] = sx2[1]; rq[1][1] = sy2[1];
                     }
-                    if (p.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                    acc[mt][nt][4 * g + 0] = v0; acc[mt][nt][4 * g + 1] = v1; acc[mt][nt][4 * g + 2] = v2; acc[mt][nt][4 * g + 3] = v3;
+#pragma unroll
+                    for (int gq = 0; gq < 2; ++gq) {
+                        const int g = 2 * gp + gq;
+                        float v0 = acc[mt][nt][4 * g + 0], v1 = acc[mt][nt][4 * g + 1], v2 = acc[mt][nt][4 * g + 2], v3 = acc[mt][nt][4 * g + 3];
+                        if constexpr (HAS_RES) {
+                            v0 += __uint_as_float(rq[gq][0] << 16); v1 += __uint_as_float(rq[gq][0] & 0xFFFF0000u);
+                            v2 += __uint_as_float(rq[gq][1] << 16); v3 += __uint_as_float(rq[gq][1] & 0xFFFF0000u);
+                        }
+                        if (p.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                        acc[mt][nt][4 * g + 0] = v0; acc[mt][nt][4 * g + 1] = v1; acc[mt][nt][4 * g + 2] = v2; acc[mt][nt][4 * g + 3] = v3;
+                    }
                 }
             // a lane holds 4 consecutive channels per accumulator quad; v_permlane32_swap trades quad g of the upper half-wave
             // for quad g+1 of the lower one: every lane then owns 8 consecutive channels of its pixel
