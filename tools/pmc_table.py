@@ -5,7 +5,8 @@ agg = defaultdict(lambda: defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"].split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            agg[name.split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
     if "conv_ring" not in k and "conv_mfma" not in k:
         continue
