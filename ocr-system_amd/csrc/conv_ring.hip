@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
                                                            unsigned long long* prof) {
     long long t_wait = 0, t_bar = 0, t_issue = 0, t_comp = 0, t_epi = 0, t0 = 0, t1 = 0;
     const long long t_begin = PROF ? clock64() : 0;
+    const unsigned long long r_begin = PROF ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz: with t_begin gives the core clock the kernel ran at
 #define RING_T(acc_) if constexpr (PROF) { t1 = clock64(); acc_ += t1 - t0; t0 = t1; }
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
             atomicAdd(prof + 2, (unsigned long long)t_issue); atomicAdd(prof + 3, (unsigned long long)t_comp);
             atomicAdd(prof + 4, (unsigned long long)t_epi); atomicAdd(prof + 5, (unsigned long long)all);
             atomicAdd(prof + 6, 1ull);
+            atomicAdd(prof + 7, __builtin_amdgcn_s_memrealtime() - r_begin);
         }
     }
 #undef RING_T
@@ -489,8 +491,8 @@ hipError_t conv_ring_launch(ConvParams p, int orientation, hipStream_t stream) {
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(hp, dprof, 64, hipMemcpyDeviceToHost);
         const double w = hp[6] ? (double)hp[6] : 1.0, all = hp[5] ? (double)hp[5] : 1.0;
-        fprintf(stderr, "[ring prof] %dx%d cin %d cout %d tr %d tiles %lld waves %.0f cycles/wave %.0f: dma-wait %.1f%% barrier %.1f%% issue+stores %.1f%% compute %.1f%% epilogue %.1f%%\n",
-                p.H, p.W, p.Cin, p.Cout, (int)tr, total, w, all / w, 100.0 * hp[0] / all, 100.0 * hp[1] / all, 100.0 * hp[2] / all, 100.0 * hp[3] / all, 100.0 * hp[4] / all);
+        fprintf(stderr, "[ring prof] %dx%d cin %d cout %d tr %d tiles %lld waves %.0f cycles/wave %.0f clock %.2f GHz: dma-wait %.1f%% barrier %.1f%% issue+stores %.1f%% compute %.1f%% epilogue %.1f%%\n",
+                p.H, p.W, p.Cin, p.Cout, (int)tr, total, w, all / w, hp[7] ? 0.1 * all / (double)hp[7] : 0.0, 100.0 * hp[0] / all, 100.0 * hp[1] / all, 100.0 * hp[2] / all, 100.0 * hp[3] / all, 100.0 * hp[4] / all);
         return hipGetLastError();
     }
     const void* fn = pool ? reinterpret_cast<const void*>(conv_ring_kernel<0, false, true>)
