@@ -44,7 +44,7 @@ def service(monkeypatch):
     fake = _FakePipeline()
     monkeypatch.setattr(s, "_ensure_engine", lambda: None)
     monkeypatch.setattr(s, "_pipeline", fake)
-    monkeypatch.setattr(s, "_upload", lambda arr: torch.from_numpy(arr))
+    monkeypatch.setattr(s, "_upload", lambda staged: staged.clone())
     monkeypatch.setattr(s, "_device_ctx", contextlib.nullcontext)
     monkeypatch.setattr(s._pre, "compress_for_azure_device",
                         lambda processed, **kw: [b"\xff\xd8" + bytes([int(processed[i, 0, 0, 0])]) for i in range(processed.shape[0])])
