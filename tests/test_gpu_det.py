@@ -271,6 +271,60 @@ def test_db_postprocess_structured_maps(engine):
     assert total > 5
 
 
+def _post_vs_oracle(engine, prob, vh, vw):
+    from oracle import dbpost
+    bits = arch.f32_to_bf16_bits(prob)
+    pd = torch.from_numpy(bits.view(np.int16)).cuda().view(torch.bfloat16)
+    boxes, scores, counts = engine.det_postprocess(pd, vh, vw)
+    torch.cuda.synchronize()
+    total = 0
+    for i in range(prob.shape[0]):
+        rb, rs, ncomp = dbpost.db_postprocess(bits[i], vh, vw)
+        n = int(counts[i])
+        assert n == len(rb), (i, n, len(rb), ncomp)
+        assert np.array_equal(boxes[i, :n].cpu().numpy(), rb), i
+        assert np.array_equal(scores[i, :n].cpu().numpy(), rs), i
+        total += n
+    return total
+
+
+def test_db_postprocess_run_list_edge_cases(engine):
+    """The components are found over row RUNS (dbpost.hip): the shapes that stress a run list — a run per other pixel (the worst case
+    the run buffer is sized for), runs that span and end exactly on 64-pixel segment borders, a width that is not a multiple of 64,
+    staircases that only touch diagonally, a comb whose teeth merge in the LAST row (late unions), empty and full maps."""
+    hp, wp, vh, vw = 96, 200, 90, 197
+    yy, xx = np.mgrid[0:hp, 0:wp]
+    maps = []
+    maps.append(np.where((xx + yy) % 2 == 0, 0.9, 0.0))                                  # checkerboard: one 8-connected component, a run per 2 pixels
+    maps.append(np.where(xx % 2 == 0, 0.9, 0.0) * (yy % 3 != 2))                           # vertical 1-pixel bars, broken every third row: thousands of small components
+    seg = np.zeros((hp, wp)); seg[10:14, 0:64] = 0.9; seg[20:24, 63:129] = 0.9; seg[30:34, 64:128] = 0.9; seg[40:44, 1:192] = 0.9; seg[50:54, 127:197] = 0.9
+    maps.append(seg)                                                                         # runs ending / starting / spanning segment borders
+    stair = np.zeros((hp, wp))
+    for k in range(40):
+        stair[5 + k, 10 + 3 * k:13 + 3 * k] = 0.9                                            # touches the row above only through a corner
+    maps.append(stair)
+    comb = np.zeros((hp, wp)); comb[5:80, 4:180:6] = 0.9; comb[79, 4:180] = 0.9               # teeth joined by the bottom row only
+    maps.append(comb)
+    maps.append(np.zeros((hp, wp)))
+    maps.append(np.full((hp, wp), 0.9))
+    rng = np.random.default_rng(9)
+    maps.append(np.where(rng.random((hp, wp)) > 0.5, 0.9, 0.0))                              # dense noise: long union chains
+    total = _post_vs_oracle(engine, np.stack(maps).astype(np.float32), vh, vw)
+    assert total >= 5   # (most of these maps are one big component; the bar map's pieces are below min_size)
+
+
+def test_db_postprocess_wide_map(engine):
+    """More than 64 segments per row (the run-fill kernel walks the segments in groups of 64 lanes)."""
+    hp, wp = 32, 4160
+    rng = np.random.default_rng(4)
+    p = np.zeros((2, hp, wp), np.float32)
+    for k in range(60):
+        x0, y0 = int(rng.integers(0, wp - 300)), int(rng.integers(0, hp - 8))
+        p[k % 2, y0:y0 + int(rng.integers(3, 8)), x0:x0 + int(rng.integers(20, 300))] = 0.8
+    p[0, 12:16, 4000:4160] = 0.8; p[1, 3:9, 4090:4100] = 0.9
+    assert _post_vs_oracle(engine, p, hp, wp) > 10
+
+
 def test_fused_head_equals_unfused(engine, any_det_weights):
     """head.convt3 fused into head.convt2's epilogue must give the same bf16 map as the two-launch path (dense weights: every
     one of the 64 channels of head.convt2 feeds the map)."""
