@@ -58,6 +58,26 @@ def test_deskew_every_stage_is_bit_exact(engine, case):
         assert abs(Engine.skew_degrees(again)[0]) < 0.5
 
 
+@pytest.mark.parametrize("hw", [(100, 130), (257, 321), (64, 64), (16, 200), (513, 65)])
+def test_hysteresis_on_noise_crosses_every_tile_border(engine, hw):
+    """The hysteresis is a union-find inside 16x64 tiles (in LDS, in the Canny kernel) plus joins across tile borders: smoothed noise
+    gives weak / strong edge chains that wander across all of them, on sizes that are and are not multiples of the tile."""
+    from oracle import deskew as od
+    h, w = hw
+    rng = np.random.default_rng(h * 1000 + w)
+    base = rng.random((h // 4 + 2, w // 4 + 2))
+    img = np.asarray(Image.fromarray((base * 255).astype(np.uint8)).resize((w, h), Image.BICUBIC), np.float32)
+    img = np.clip(img + rng.normal(0, 6, (h, w)), 0, 255).astype(np.uint8)
+    page = np.ascontiguousarray(np.repeat(img[..., None], 3, axis=2))
+    pages = np.stack([page, np.ascontiguousarray(page[::-1, ::-1])])
+    edges = engine.deskew(torch.from_numpy(pages).cuda(), debug=True)[3]
+    torch.cuda.synchronize()
+    for i in range(2):
+        ref = od.canny(pages[i])
+        assert np.array_equal(edges[i].cpu().numpy(), ref), (hw, i, int((ref > 0).sum()))
+    assert int((od.canny(pages[0]) > 0).sum()) > h * w // 50
+
+
 def test_deskew_flags_skip_small_and_large_angles_and_blank_pages(engine):
     """< 0.5 degrees: unchanged, angle reported; > 45: unchanged, angle 0.0 (:441-447); no line at all: unchanged (:409-411)."""
     from oracle import deskew as od
