@@ -232,7 +232,7 @@ def main():
                        "parallelism": "pages sharded dp%d, 1 all-gather/step" % world,
                        "ranks": ranks_seen, "collective_backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if distributed else None,
                        "input": "pages pre-decoded (uint8 RGB) and resident in HBM when the timed region starts",
-                       "outside_timed_region": "image decode, host->device copy, JPEG hand-off of the processed page (3.7 ms per 64 pages on the device)",
+                       "outside_timed_region": "image decode, host->device copy, JPEG hand-off of the processed page (2.5 ms per 64 pages on the device)",
                        "det_sub_batch": args.det_sub_batch,
                        "deskew": ("on" if args.deskew else "off: not part of det+rec; the reference's deskew needs OpenCV and is a no-op without it (image_preprocessing.py:383-385); "
                                   "on the device it costs ~12 ms per 64 pages (DESIGN.md), run with --deskew to include it")},

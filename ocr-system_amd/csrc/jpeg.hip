@@ -203,75 +203,102 @@ __global__ __launch_bounds__(256) void jpeg_stats_kernel(const int16_t* coefs, G
 }
 
 // ---- 4: optimal Huffman table, one wave per (page, table) ----
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), m), hi = __shfl_xor((unsigned)(v >> 32), m);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        v = o < v ? o : v;
-    }
-    return v;
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), m), hi = __shfl_xor((unsigned)(v >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
 }
 __global__ __launch_bounds__(64) void jpeg_tables_kernel(const uint32_t* hist, DevHT* tabs) {
-    __shared__ int freq[257], codesize[257], others[257], bits[33];
+    // libjpeg's jpeg_gen_optimal_table: up to 256 rounds of "merge the two least frequent trees" (ties -> the LARGER symbol), each
+    // bumping the code size of every member of both trees by walking their `others` chains.  Here the 257 frequencies, code sizes and
+    // tree labels (a symbol remembers the first symbol of its tree) live in registers, 5 per lane; a round is one butterfly that
+    // carries the two smallest keys at once, and the bump / re-label of the members is a compare per register: the same
+    // increments, no LDS round trip in the loop (the serial version took 0.65 ms per table, this one ~0.15).
+    __shared__ int codesize[257], bits[33];
     const int t = blockIdx.x, lane = threadIdx.x;
-    for (int i = lane; i < 257; i += 64) { freq[i] = i < 256 ? (int)hist[(size_t)t * 256 + i] : 1; codesize[i] = 0; others[i] = -1; }
+    int f[5], cs[5], tr[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int i = lane + 64 * j;
+        f[j] = i < 256 ? (int)hist[(size_t)t * 256 + i] : (i == 256 ? 1 : 0);
+        cs[j] = 0; tr[j] = i;
+    }
     if (lane < 33) bits[lane] = 0;
-    __syncthreads();
     const unsigned long long NONE = ~0ull;
     for (;;) {
-        // smallest non-zero frequency, ties -> the LARGER symbol: key = freq << 16 | (0xFFFF - symbol), minimum wins
-        unsigned long long k1 = NONE;
-        for (int i = lane; i < 257; i += 64) {
-            const int f = freq[i];
-            if (f) { const unsigned long long k = ((unsigned long long)f << 16) | (unsigned)(0xFFFF - i); k1 = k < k1 ? k : k1; }
+        // key = freq << 16 | (0xFFFF - symbol): the minimum is the smallest non-zero frequency, ties -> the larger symbol
+        unsigned long long a1 = NONE, a2 = NONE;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            if (f[j]) {
+                const unsigned long long k = ((unsigned long long)f[j] << 16) | (unsigned)(0xFFFF - (lane + 64 * j));
+                if (k < a1) { a2 = a1; a1 = k; } else if (k < a2) a2 = k;
+            }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {   // the keys are distinct and the two halves of a butterfly step hold disjoint sets
+            const unsigned long long b1 = shfl_xor_u64(a1, m), b2 = shfl_xor_u64(a2, m);
+            const unsigned long long lo = a1 < b1 ? a1 : b1, hi = a1 < b1 ? b1 : a1, s2 = a2 < b2 ? a2 : b2;
+            a1 = lo; a2 = hi < s2 ? hi : s2;
         }
-        k1 = wave_min_u64(k1);
-        const int c1 = 0xFFFF - (int)(k1 & 0xFFFF);
-        unsigned long long k2 = NONE;
-        for (int i = lane; i < 257; i += 64) {
-            const int f = freq[i];
-            if (f && i != c1) { const unsigned long long k = ((unsigned long long)f << 16) | (unsigned)(0xFFFF - i); k2 = k < k2 ? k : k2; }
+        if (a2 == NONE) break;
+        const int c1 = 0xFFFF - (int)(a1 & 0xFFFF), c2 = 0xFFFF - (int)(a2 & 0xFFFF), f2 = (int)(a2 >> 16);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int i = lane + 64 * j;
+            if (i == c1) f[j] += f2;
+            if (i == c2) f[j] = 0;
+            if (tr[j] == c1 || tr[j] == c2) { cs[j]++; tr[j] = c1; }
         }
-        k2 = wave_min_u64(k2);
-        if (k2 == NONE) break;
-        const int c2 = 0xFFFF - (int)(k2 & 0xFFFF);
-        if (lane == 0) {
-            freq[c1] += freq[c2]; freq[c2] = 0;
-            int a = c1;
-            codesize[a]++;
-            while (others[a] >= 0) { a = others[a]; codesize[a]++; }
-            others[a] = c2;
-            a = c2;
-            codesize[a]++;
-            while (others[a] >= 0) { a = others[a]; codesize[a]++; }
-        }
-        __syncthreads();
     }
-    if (lane != 0) return;
-    for (int i = 0; i <= 256; ++i) if (codesize[i]) bits[codesize[i] > 32 ? 32 : codesize[i]]++;
-    for (int i = 32; i > 16; --i)
-        while (bits[i] > 0) {
-            int j = i - 2;
-            while (bits[j] == 0) --j;
-            bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
-        }
-    int i = 16;
-    while (i > 0 && bits[i] == 0) --i;
-    if (i > 0) bits[i]--;  // the pseudo-symbol 256 reserved the all-ones code
+#pragma unroll
+    for (int j = 0; j < 5; ++j) if (lane + 64 * j < 257) codesize[lane + 64 * j] = cs[j];
+    __syncthreads();
+    // The rest of jpeg_gen_optimal_table + the canonical code assignment, with only the 16-step length bookkeeping left to one lane
+    // (the serial "for every length, for every symbol" sweeps were 0.4 ms per table).
+    __shared__ int first_k[18], code_start[18];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) if (lane + 64 * j < 257 && cs[j]) atomicAdd(&bits[cs[j] > 32 ? 32 : cs[j]], 1);
+    __syncthreads();
     DevHT* T = tabs + t;
-    T->bits[0] = 0;
-    for (int k = 1; k <= 16; ++k) T->bits[k] = (uint8_t)bits[k];
-    int p = 0;
-    for (int len = 1; len <= 32; ++len)
-        for (int s = 0; s < 256; ++s) if (codesize[s] == len) T->vals[p++] = (uint8_t)s;
-    T->nval = (uint32_t)p;
-    for (int s = 0; s < 256; ++s) { T->size[s] = 0; T->code[s] = 0; }
-    int k = 0, code = 0;
-    for (int len = 1; len <= 16; ++len) {
-        for (int j = 0; j < bits[len]; ++j, ++k) { T->code[T->vals[k]] = (uint16_t)code++; T->size[T->vals[k]] = (uint8_t)len; }
-        code <<= 1;
+    if (lane == 0) {
+        for (int i = 32; i > 16; --i)
+            while (bits[i] > 0) {
+                int j = i - 2;
+                while (bits[j] == 0) --j;
+                bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
+            }
+        int i = 16;
+        while (i > 0 && bits[i] == 0) --i;
+        if (i > 0) bits[i]--;  // the pseudo-symbol 256 reserved the all-ones code
+        T->bits[0] = 0;
+        int k = 0, code = 0;
+        for (int len = 1; len <= 16; ++len) {
+            T->bits[len] = (uint8_t)bits[len];
+            first_k[len] = k; code_start[len] = code;
+            k += bits[len]; code = (code + bits[len]) << 1;
+        }
+        first_k[17] = k;
     }
+    __syncthreads();
+    // huffval = the symbols 0..255 in order of (code size, symbol): a symbol's position is the number of symbols before it
+    int nval = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int sym = lane + 64 * j, mine = cs[j];
+        int rank = 0;
+        for (int o = 0; o < 256; ++o) {
+            const int oc = codesize[o];
+            rank += (oc != 0 && (oc < mine || (oc == mine && o < sym))) ? 1 : 0;
+            if (j == 0 && lane == 0) nval += oc != 0;
+        }
+        uint16_t code = 0; uint8_t size = 0;
+        if (mine) {
+            T->vals[rank] = (uint8_t)sym;
+            for (int len = 1; len <= 16; ++len)
+                if (rank >= first_k[len] && rank < first_k[len + 1]) { size = (uint8_t)len; code = (uint16_t)(code_start[len] + rank - first_k[len]); }
+        }
+        T->size[sym] = size; T->code[sym] = code;
+    }
+    if (lane == 0) T->nval = (uint32_t)nval;
 }
 
 // ---- 4': the ITU-T T.81 Annex K.3 typical tables (optimize == 0: what libjpeg writes without the statistics pass) ----
@@ -366,10 +393,13 @@ __global__ __launch_bounds__(256) void jpeg_scan_kernel(uint32_t* blkbits, Geo g
     uint32_t* a = blkbits + (size_t)page * g.nblk;
     if (tid == 0) run = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < g.nblk; i0 += 256) {
-        const int i = i0 + tid;
-        const uint32_t v = i < g.nblk ? a[i] : 0;
-        uint32_t inc = v;
+    constexpr int PER = 8;   // blocks per thread and round: three barriers per 2048 blocks instead of per 256
+    for (int i0 = 0; i0 < g.nblk; i0 += 256 * PER) {
+        const int ib = i0 + tid * PER;
+        uint32_t v[PER], tot = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { v[k] = ib + k < g.nblk ? a[ib + k] : 0; tot += v[k]; }
+        uint32_t inc = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
         if (lane == 63) wsum[wave] = inc;
@@ -377,7 +407,9 @@ __global__ __launch_bounds__(256) void jpeg_scan_kernel(uint32_t* blkbits, Geo g
         uint32_t woff = 0;
         for (int w2 = 0; w2 < wave; ++w2) woff += wsum[w2];
         const unsigned long long base = run;
-        if (i < g.nblk) a[i] = (uint32_t)(base + woff + inc - v);   // offsets fit 32 bits (checked against the raw capacity in finish)
+        uint32_t off = (uint32_t)(base + woff + inc - tot);   // offsets fit 32 bits (checked against the raw capacity in finish)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { if (ib + k < g.nblk) a[ib + k] = off; off += v[k]; }
         __syncthreads();
         if (tid == 0) run = base + wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
@@ -449,89 +481,120 @@ __global__ __launch_bounds__(256) void jpeg_emit_kernel(const int16_t* coefs, Ge
 }
 
 // ---- 8: headers + byte stuffing + EOI -> the finished file ----
-__global__ __launch_bounds__(256) void jpeg_finish_kernel(const uint32_t* raw, size_t raw_words_per_page, const unsigned long long* totalbits, const DevHT* tabs,
-                                                          Geo g, QTab q, uint8_t* out, size_t out_stride, int32_t* sizes) {
+// Every 0xFF byte of the entropy-coded stream is followed by a stuffed 0x00, so a byte's place in the file depends on the 0xFF bytes
+// before it.  Three steps (one work-group per page walking the stream with three barriers per 4 KB took 0.6 ms per page, whatever
+// the batch): 8a counts the 0xFF bytes of every 4 KB piece, 8b writes the headers, scans the piece counts and closes the file,
+// 8c moves the pieces to their places.
+constexpr int FIN_PIECE = 256 * 16;
+// the 16 stream bytes of thread-slot kb (the last byte of the stream is padded with ones) -> by[], returns how many are 0xFF
+__device__ __forceinline__ uint32_t stream_bytes16(const uint32_t* rw, unsigned long long kb, unsigned long long nbytes, unsigned long long tb, uint8_t* by) {
+    uint32_t nff = 0;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) {
+        const unsigned long long wi = (kb >> 2) + wv;
+        const uint32_t w = (wi * 4 < nbytes) ? rw[wi] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long k = kb + wv * 4 + j;
+            uint32_t bv = (w >> (24 - 8 * j)) & 0xffu;
+            if (k == nbytes - 1 && (tb & 7)) bv |= 0xffu >> (tb & 7);  // pad the last byte with ones
+            by[wv * 4 + j] = (uint8_t)bv;
+            if (k < nbytes && bv == 0xffu) ++nff;
+        }
+    }
+    return nff;
+}
+__global__ __launch_bounds__(256) void jpeg_ffcount_kernel(const uint32_t* raw, size_t raw_words_per_page, const unsigned long long* totalbits, uint32_t* ffcnt,
+                                                           int pieces) {
     __shared__ uint32_t wsum[4];
-    __shared__ unsigned long long run;
-    __shared__ int hdr_len;
-    const int page = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int page = blockIdx.y, piece = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long tb = totalbits[page], nbytes = (tb + 7) >> 3;
+    const unsigned long long kb = (unsigned long long)piece * FIN_PIECE + (unsigned long long)tid * 16;
+    uint32_t nff = 0;
+    if (kb < nbytes && nbytes + 4 <= raw_words_per_page * 4) {
+        uint8_t by[16];
+        nff = stream_bytes16(raw + (size_t)page * raw_words_per_page, kb, nbytes, tb, by);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) nff += __shfl_xor(nff, m);
+    if (lane == 0) wsum[wave] = nff;
+    __syncthreads();
+    if (tid == 0) ffcnt[(size_t)page * pieces + piece] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(64) void jpeg_head_kernel(const unsigned long long* totalbits, size_t raw_words_per_page, const DevHT* tabs, Geo g, QTab q, uint32_t* ffcnt,
+                                                       int pieces, int* hdr_len, uint8_t* out, size_t out_stride, int32_t* sizes) {
+    const int page = blockIdx.x, lane = threadIdx.x;
     uint8_t* o = out + (size_t)page * out_stride;
     const DevHT* T = tabs + (size_t)page * 4;
-    const unsigned long long tb = totalbits[page];
-    const unsigned long long nbytes = (tb + 7) >> 3;
+    const unsigned long long tb = totalbits[page], nbytes = (tb + 7) >> 3;
     const bool overflow = nbytes + 4 > raw_words_per_page * 4;
-    if (tid == 0) {
-        size_t p = 0;
-        auto put = [&](int v) { if (p < out_stride) o[p] = (uint8_t)v; ++p; };
-        auto put16 = [&](int v) { put(v >> 8); put(v & 0xff); };
-        put(0xFF); put(0xD8);
-        put(0xFF); put(0xE0); put16(16);
-        const uint8_t jf[14] = {'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
-        for (int i = 0; i < 14; ++i) put(jf[i]);
-        for (int t = 0; t < 2; ++t) {
-            put(0xFF); put(0xDB); put16(67); put(t);
-            for (int i = 0; i < 64; ++i) put((t ? q.c : q.l)[d_ZZ[i]]);
-        }
-        put(0xFF); put(0xC0); put16(17); put(8); put16(g.h); put16(g.w); put(3);
-        put(1); put(0x22); put(0); put(2); put(0x11); put(1); put(3); put(0x11); put(1);
-        for (int t = 0; t < 2; ++t)
-            for (int a = 0; a < 2; ++a) {
-                const DevHT& H = T[t * 2 + a];
-                put(0xFF); put(0xC4); put16(2 + 1 + 16 + (int)H.nval); put((a << 4) | t);
-                for (int i = 1; i <= 16; ++i) put(H.bits[i]);
-                for (uint32_t i = 0; i < H.nval; ++i) put(H.vals[i]);
-            }
-        put(0xFF); put(0xDA); put16(12); put(3); put(1); put(0x00); put(2); put(0x11); put(3); put(0x11); put(0); put(63); put(0);
-        hdr_len = (int)p;
-        run = 0;
-    }
-    __syncthreads();
-    const size_t hl = (size_t)hdr_len;
-    const uint32_t* rw = raw + (size_t)page * raw_words_per_page;
-    // each thread: 16 stream bytes per round; 0xFF bytes are followed by a stuffed 0x00
-    for (unsigned long long k0 = 0; k0 < nbytes && !overflow; k0 += 256 * 16) {
-        const unsigned long long kb = k0 + (unsigned long long)tid * 16;
-        uint8_t by[16];
-        uint32_t nff = 0;
-#pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
-            const unsigned long long wi = (kb >> 2) + wv;
-            uint32_t w = (wi * 4 < nbytes) ? rw[wi] : 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned long long k = kb + wv * 4 + j;
-                uint32_t bv = (w >> (24 - 8 * j)) & 0xffu;
-                if (k == nbytes - 1 && (tb & 7)) bv |= 0xffu >> (tb & 7);  // pad the last byte with ones
-                by[wv * 4 + j] = (uint8_t)bv;
-                if (k < nbytes && bv == 0xffu) ++nff;
-            }
-        }
-        uint32_t inc = nff;
+    // piece counts -> exclusive offsets (in place), 64 pieces per step
+    uint32_t* fc = ffcnt + (size_t)page * pieces;
+    uint32_t run = 0;
+    for (int p0 = 0; p0 < pieces; p0 += 64) {
+        const int pi = p0 + lane;
+        const uint32_t v = pi < pieces ? fc[pi] : 0u;
+        uint32_t inc = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t ov = __shfl_up(inc, d); if (lane >= d) inc += ov; }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w2 = 0; w2 < wave; ++w2) woff += wsum[w2];
-        const unsigned long long base = run;
-        size_t p = hl + (size_t)kb + (size_t)(base + woff + inc - nff);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (kb + j >= nbytes) break;
-            if (p < out_stride) o[p] = by[j];
-            ++p;
-            if (by[j] == 0xff) { if (p < out_stride) o[p] = 0; ++p; }
-        }
-        __syncthreads();
-        if (tid == 0) run = base + wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
+        if (pi < pieces) fc[pi] = run + inc - v;
+        run += __shfl(inc, 63);
     }
-    if (tid == 0) {
-        const unsigned long long total = hl + nbytes + run + 2;
-        size_t p = hl + (size_t)nbytes + (size_t)run;
-        if (p < out_stride) o[p] = 0xFF;
-        if (p + 1 < out_stride) o[p + 1] = 0xD9;
-        sizes[page] = (!overflow && total <= out_stride && total < 0x7fffffffull) ? (int32_t)total : -(int32_t)(total < 0x7fffffffull ? total : 0x7fffffff);
+    if (lane != 0) return;
+    size_t p = 0;
+    auto put = [&](int v) { if (p < out_stride) o[p] = (uint8_t)v; ++p; };
+    auto put16 = [&](int v) { put(v >> 8); put(v & 0xff); };
+    put(0xFF); put(0xD8);
+    put(0xFF); put(0xE0); put16(16);
+    const uint8_t jf[14] = {'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
+    for (int i = 0; i < 14; ++i) put(jf[i]);
+    for (int t = 0; t < 2; ++t) {
+        put(0xFF); put(0xDB); put16(67); put(t);
+        for (int i = 0; i < 64; ++i) put((t ? q.c : q.l)[d_ZZ[i]]);
+    }
+    put(0xFF); put(0xC0); put16(17); put(8); put16(g.h); put16(g.w); put(3);
+    put(1); put(0x22); put(0); put(2); put(0x11); put(1); put(3); put(0x11); put(1);
+    for (int t = 0; t < 2; ++t)
+        for (int a = 0; a < 2; ++a) {
+            const DevHT& H = T[t * 2 + a];
+            put(0xFF); put(0xC4); put16(2 + 1 + 16 + (int)H.nval); put((a << 4) | t);
+            for (int i = 1; i <= 16; ++i) put(H.bits[i]);
+            for (uint32_t i = 0; i < H.nval; ++i) put(H.vals[i]);
+        }
+    put(0xFF); put(0xDA); put16(12); put(3); put(1); put(0x00); put(2); put(0x11); put(3); put(0x11); put(0); put(63); put(0);
+    const size_t hl = p;
+    hdr_len[page] = (int)hl;
+    const unsigned long long stuffed = overflow ? 0ull : (unsigned long long)run;
+    const unsigned long long total = hl + nbytes + stuffed + 2;
+    p = hl + (size_t)nbytes + (size_t)stuffed;
+    if (p < out_stride) o[p] = 0xFF;
+    if (p + 1 < out_stride) o[p + 1] = 0xD9;
+    sizes[page] = (!overflow && total <= out_stride && total < 0x7fffffffull) ? (int32_t)total : -(int32_t)(total < 0x7fffffffull ? total : 0x7fffffff);
+}
+__global__ __launch_bounds__(256) void jpeg_stuff_kernel(const uint32_t* raw, size_t raw_words_per_page, const unsigned long long* totalbits, const uint32_t* ffoff,
+                                                         int pieces, const int* hdr_len, uint8_t* out, size_t out_stride) {
+    __shared__ uint32_t wsum[4];
+    const int page = blockIdx.y, piece = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long tb = totalbits[page], nbytes = (tb + 7) >> 3;
+    const unsigned long long k0 = (unsigned long long)piece * FIN_PIECE, kb = k0 + (unsigned long long)tid * 16;
+    if (k0 >= nbytes || nbytes + 4 > raw_words_per_page * 4) return;   // (work-group-uniform)
+    uint8_t by[16];
+    const uint32_t nff = stream_bytes16(raw + (size_t)page * raw_words_per_page, kb, nbytes, tb, by);
+    uint32_t inc = nff;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t ov = __shfl_up(inc, d); if (lane >= d) inc += ov; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w2 = 0; w2 < wave; ++w2) woff += wsum[w2];
+    uint8_t* o = out + (size_t)page * out_stride;
+    size_t p = (size_t)hdr_len[page] + (size_t)kb + (size_t)ffoff[(size_t)page * pieces + piece] + (size_t)(woff + inc - nff);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (kb + j >= nbytes) break;
+        if (p < out_stride) o[p] = by[j];
+        ++p;
+        if (by[j] == 0xff) { if (p < out_stride) o[p] = 0; ++p; }
     }
 }
 
@@ -562,7 +625,8 @@ size_t jpeg_workspace_bytes(int n, int height, int width) {
     const Geo g = make_geo(height, width);
     const size_t coef = al256((size_t)n * g.nblk * 64 * 2), hist = al256((size_t)n * 1024 * 4), tabs = al256((size_t)n * 4 * sizeof(DevHT));
     const size_t bb = al256((size_t)n * g.nblk * 4), tbits = al256((size_t)n * 8), raw = al256((size_t)n * ((size_t)g.nblk * 128 + 64));
-    return coef + hist + tabs + bb + tbits + raw;
+    const size_t pieces = ((size_t)g.nblk * 128 + 64 + FIN_PIECE - 1) / FIN_PIECE;
+    return coef + hist + tabs + bb + tbits + raw + al256((size_t)n * pieces * 4) + al256((size_t)n * 4);
 }
 
 hipError_t jpeg_coefficients_launch(const uint8_t* rgb, int n, int height, int width, int quality, int16_t* coefs, hipStream_t st) {
@@ -586,6 +650,9 @@ hipError_t jpeg_encode_launch(const JpegParams& p, void* workspace, hipStream_t 
     unsigned long long* totalbits = static_cast<unsigned long long*>(take((size_t)p.n * 8));
     const size_t raw_words = ((size_t)g.nblk * 128 + 64) / 4;
     uint32_t* raw = static_cast<uint32_t*>(take((size_t)p.n * raw_words * 4));
+    const int pieces = (int)((raw_words * 4 + FIN_PIECE - 1) / FIN_PIECE);
+    uint32_t* ffcnt = static_cast<uint32_t*>(take((size_t)p.n * pieces * 4));
+    int* hdrlen = static_cast<int*>(take((size_t)p.n * 4));
     hipError_t e = hipMemsetAsync(hist, 0, (size_t)p.n * 1024 * 4, st);
     if (e == hipSuccess) e = hipMemsetAsync(raw, 0, (size_t)p.n * raw_words * 4, st);
     if (e != hipSuccess) return e;
@@ -601,6 +668,8 @@ hipError_t jpeg_encode_launch(const JpegParams& p, void* workspace, hipStream_t 
     hipLaunchKernelGGL(jpeg_blockbits_kernel, gb, dim3(256), 0, st, coefs, g, tabs, blkbits);
     hipLaunchKernelGGL(jpeg_scan_kernel, dim3(p.n), dim3(256), 0, st, blkbits, g, totalbits);
     hipLaunchKernelGGL(jpeg_emit_kernel, gb, dim3(256), 0, st, coefs, g, tabs, blkbits, raw, raw_words);
-    hipLaunchKernelGGL(jpeg_finish_kernel, dim3(p.n), dim3(256), 0, st, raw, raw_words, totalbits, tabs, g, q, p.out, p.out_stride, p.sizes);
+    hipLaunchKernelGGL(jpeg_ffcount_kernel, dim3(pieces, p.n), dim3(256), 0, st, raw, raw_words, totalbits, ffcnt, pieces);
+    hipLaunchKernelGGL(jpeg_head_kernel, dim3(p.n), dim3(64), 0, st, totalbits, raw_words, tabs, g, q, ffcnt, pieces, hdrlen, p.out, p.out_stride, p.sizes);
+    hipLaunchKernelGGL(jpeg_stuff_kernel, dim3(pieces, p.n), dim3(256), 0, st, raw, raw_words, totalbits, ffcnt, pieces, hdrlen, p.out, p.out_stride);
     return hipGetLastError();
 }
