@@ -120,7 +120,8 @@ int lumina_ocr_det_postprocess(lumina_ocr_t* h, const uint16_t* prob_dev, int ba
     if (batch <= 0 || max_boxes <= 0 || valid_h > hp || valid_w > wp) return locr_fail(h, "det_postprocess", "bad dimensions");
     BIND(h);
     API_TRY
-    // pages are processed in groups that bound the workspace (~72 MB of labels / row-extreme segments per A4 page)
+    // pages are processed in groups that bound the workspace (~66 MB per A4 page: worst-case run list + row-extreme segments and hull scratch
+    // of max_boxes page-high candidates)
     const int group = h->post_group;
     for (int b0 = 0; b0 < batch; b0 += group) {
         const int nb = batch - b0 < group ? batch - b0 : group;
