@@ -627,7 +627,7 @@ size_t deskew_workspace_bytes(int B, int H, int W) {
 
 hipError_t deskew_launch(const DeskewParams& p, void* workspace, hipStream_t st) {
     const int B = p.B, H = p.H, W = p.W;
-    if (B <= 0 || H < 8 || W < 8 || H >= 32768 || W >= 32768) return hipErrorInvalidValue;   // (H * W >= 64: a wave spans at most two pages)
+    if (B <= 0 || H <= 0 || W <= 0 || H >= 32768 || W >= 32768) return hipErrorInvalidValue;
     const size_t per = (size_t)H * W, px = (size_t)B * per;
     if (px >= (1ull << 40) || per >= (1ull << 31)) return hipErrorInvalidValue;
     const int numrho = 2 * (W + H) + 1;

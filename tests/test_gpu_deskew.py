@@ -78,6 +78,24 @@ def test_hysteresis_on_noise_crosses_every_tile_border(engine, hw):
     assert int((od.canny(pages[0]) > 0).sum()) > h * w // 50
 
 
+@pytest.mark.parametrize("hw", [(1, 1), (5, 7), (300, 7), (3, 1000), (7, 64), (2, 130)])
+def test_strips_narrower_than_a_tile(engine, hw):
+    """Degenerate pages (a side shorter than the 16x64 tile, down to one pixel): every stage still agrees with the oracle."""
+    from oracle import deskew as od
+    h, w = hw
+    rng = np.random.default_rng(h * 31 + w)
+    page = np.ascontiguousarray((rng.integers(0, 2, (h, w, 1)) * 200 + rng.integers(0, 40, (h, w, 3))).astype(np.uint8))
+    out, rot, info, edges, segs, nsegs = engine.deskew(torch.from_numpy(page[None].copy()).cuda(), debug=True)
+    torch.cuda.synchronize()
+    ref_edges = od.canny(page)
+    assert np.array_equal(edges[0].cpu().numpy(), ref_edges)
+    ref_segs, ref_peaks = od.segments(ref_edges)
+    assert _segset(segs[0].cpu().numpy(), nsegs[0].cpu().numpy()) == sorted(tuple(int(v) for v in s) for s in ref_segs)
+    assert info[0].tolist() == [len(ref_segs), ref_peaks]
+    assert np.array_equal(rot[0].cpu().numpy(), od.angle(ref_segs))
+    assert np.array_equal(out[0].cpu().numpy(), od.deskew(page)[0])
+
+
 def test_deskew_flags_skip_small_and_large_angles_and_blank_pages(engine):
     """< 0.5 degrees: unchanged, angle reported; > 45: unchanged, angle 0.0 (:441-447); no line at all: unchanged (:409-411)."""
     from oracle import deskew as od

@@ -81,3 +81,22 @@ def test_deskew_flag_is_honoured(service):
         v = [abs((b["polygon"][3] - b["polygon"][1]) / max(b["polygon"][2] - b["polygon"][0], 1.0)) for b in o.layout_boxes if b["type"] == "line"]
         return float(np.mean(v)) if v else 1.0
     assert slope(on) < 0.5 * slope(off) or slope(on) < 0.01, (slope(on), slope(off))
+
+
+@pytest.mark.parametrize("size", [(1, 1), (5, 7), (7, 300), (1000, 3), (31, 33), (257, 4099), (2001, 5)])
+@pytest.mark.parametrize("mode", ["RGB", "L"])
+def test_degenerate_page_sizes_are_processed(service, size, mode):
+    """One-pixel pages, strips thinner than any kernel tile, a strip longer than the 2000-px cap, grayscale input (the reference
+    passes 'L' images through load_image, image_preprocessing.py:57-75): the provider answers with a page, never with an error —
+    with de-skew on, as in the reference's default configuration."""
+    w, h = size
+    rng = np.random.default_rng(w * 7 + h)
+    a = rng.integers(0, 256, (h, w, 3) if mode == "RGB" else (h, w), dtype=np.uint8)
+    service.apply_deskew = True
+    out = service.process_image_sync(Image.fromarray(a, mode))
+    assert out.success, out.error
+    assert (out.image_width, out.image_height) == (w, h)
+    assert out.page_width_inches >= 1 and out.page_height_inches >= 1 and max(out.page_width_inches, out.page_height_inches) <= 2000
+    assert out.processed_image_bytes[:2] == b"\xff\xd8" and out.processed_image_bytes[-2:] == b"\xff\xd9"
+    im = Image.open(io.BytesIO(out.processed_image_bytes))
+    assert im.size == (int(out.page_width_inches), int(out.page_height_inches))
