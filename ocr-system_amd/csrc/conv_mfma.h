@@ -67,6 +67,7 @@ const char* conv_kernel_name(const ConvKernelCfg& cfg);
 bool conv_ring_supported(const ConvKernelCfg& cfg, const ConvParams& p);
 bool conv_ring_transposed(const ConvParams& p, int orientation);
 hipError_t conv_ring_launch(ConvParams p, int orientation, hipStream_t stream);
+const char* conv_ring_kernel_name(const ConvParams& p, int orientation);
 
 // Pixel-stationary pointwise kernel (conv_pw.hip) for Cin 64 / 128, all output channels per workgroup; same packed weights
 // (bn 64, ck 32).  Output modes: OUT_NORMAL (optional top-down add) and OUT_CONVT with the fused DBHead tail.

@@ -29,7 +29,7 @@ namespace {
 constexpr int R_TH = 16, R_TW = 32, R_HH = 18, R_HW = 34, R_BN = 64, R_MT = 4, R_NT = 2;
 constexpr int R_A_ITEMS = R_HH * R_HW * 2;   // 16-byte pieces of one chunk's halo tile, [pixel][2 slices]
 constexpr int R_W_ITEMS = 9 * R_BN * 2;      // ... of one chunk's weight slab, [tap * 64 + n][2 slices]
-constexpr int R_AIT = (R_A_ITEMS + 255) / 256, R_WIT = (R_W_ITEMS + 255) / 256;
+constexpr int R_AIT = (R_A_ITEMS + 255) / 256;
 constexpr int R_A_BYTES = R_AIT * 256 * 16;  // padded to whole rounds of 256 pieces: every halo DMA is a full, branch-free instruction
 constexpr int R_W_BYTES = R_W_ITEMS * 16, R_BUF = R_A_BYTES + R_W_BYTES;
 constexpr int R_BIAS_BYTES = 4096;           // the layer's bias vector (<= 1024 output channels)
@@ -41,9 +41,21 @@ struct RingTile { int n_img, ntile, oyb, oxb; };
 __device__ __forceinline__ bf16x8_t ring_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 
 // PROF (developer tool, LUMINA_RING_PROF=1): per-phase core-clock sums of every wave -> prof[0..7] (see conv_ring_launch)
-template <int TR, bool PROF = false, bool POOL = false>
-__global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, const int total_tiles, const int per_xcd, const int wg_per_xcd,
+// NWV = 8: 8 waves = a 32 x 32-pixel tile, ONE work-group per CU — the weight slab of a chunk serves twice the MFMAs (8 LDS-DMA requests
+// per wave and chunk instead of 10), the halo overlaps less with its neighbours.  Same fragments, same summation order: bit-identical.
+template <int NWV> struct RingCfg {
+    static constexpr int NTHR = 64 * NWV, TH = R_MT * NWV, HH = TH + 2, A_ITEMS = HH * R_HW * 2;
+    static constexpr int AIT = (A_ITEMS + NTHR - 1) / NTHR, WIT = (R_W_ITEMS + NTHR - 1) / NTHR;
+    static constexpr int A_BYTES = AIT * NTHR * 16, BUF = A_BYTES + R_W_BYTES, LDS = 2 * BUF + R_BIAS_BYTES;
+};
+static_assert(RingCfg<4>::LDS == R_LDS && RingCfg<8>::LDS <= 160 * 1024, "LDS budget");
+
+template <int TR, bool PROF = false, bool POOL = false, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_ring_kernel(const ConvParams p, const int total_tiles, const int per_xcd, const int wg_per_xcd,
                                                            unsigned long long* prof) {
+    // (the tile constants of this instantiation shadow the 4-wave ones declared at namespace scope)
+    constexpr int NTHR = RingCfg<NWV>::NTHR, R_TH = RingCfg<NWV>::TH, R_A_ITEMS = RingCfg<NWV>::A_ITEMS, R_AIT = RingCfg<NWV>::AIT;
+    constexpr int R_WIT = RingCfg<NWV>::WIT, R_A_BYTES = RingCfg<NWV>::A_BYTES, R_BUF = RingCfg<NWV>::BUF;
     long long t_wait = 0, t_bar = 0, t_issue = 0, t_comp = 0, t_epi = 0, t0 = 0, t1 = 0;
     const long long t_begin = PROF ? clock64() : 0;
     const unsigned long long r_begin = PROF ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz: with t_begin gives the core clock the kernel ran at
@@ -92,8 +104,8 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
     unsigned a_item[(R_AIT + 1) / 2];
 #pragma unroll
     for (int it = 0; it < R_AIT; ++it) {
-        const int i = tid + 256 * it, pi = i >> 1, hy = pi / R_HW, hx = pi - hy * R_HW;
-        const unsigned e = (unsigned)hy | ((unsigned)hx << 5) | ((unsigned)(i & 1) << 11) | ((unsigned)(i < R_A_ITEMS) << 12);
+        const int i = tid + NTHR * it, pi = i >> 1, hy = pi / R_HW, hx = pi - hy * R_HW;
+        const unsigned e = (unsigned)hy | ((unsigned)hx << 6) | ((unsigned)(i & 1) << 12) | ((unsigned)(i < R_A_ITEMS) << 13);
         if (it & 1) a_item[it >> 1] |= e << 16; else a_item[it >> 1] = e;
     }
     // ... and their global offsets for the tile / source being requested
@@ -105,14 +117,14 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
 #pragma unroll
         for (int it = 0; it < R_AIT; ++it) {
             const unsigned e = (a_item[it >> 1] >> (16 * (it & 1))) & 0xffffu;
-            const int hy = e & 31, hx = (e >> 5) & 63, c = (e >> 11) & 1;
+            const int hy = e & 63, hx = (e >> 6) & 63, c = (e >> 12) & 1;
             const int ly = t.oyb - 1 + hy, lx = t.oxb - 1 + hx;
-            const bool inb = (e >> 12) != 0 && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
+            const bool inb = (e >> 13) != 0 && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
             const int cs = c ^ ((hx >> 3) & 1);   // LDS slot c of this pixel holds slice cs (bank swizzle, see the fragment reads)
             const int iy = TR ? lx : ly, ix = TR ? ly : lx;   // image row / column of the halo pixel
             const int pix = nsrc > 1 ? (iy >> sh) * ws + (ix >> sh) : ly * sy + lx * sx;   // nearest-upsampled read of a low-resolution source
             a_goff[it] = inb ? pix * (p.x_blk ? 16 : cin_s) + cs * 8 : -1;
-            if (PROF && (p.dbg_skip & 8)) a_goff[it] = (tid + 256 * it) * 8;   // timing experiment: a perfectly coalesced halo (wrong values)
+            if (PROF && (p.dbg_skip & 8)) a_goff[it] = (tid + NTHR * it) * 8;   // timing experiment: a perfectly coalesced halo (wrong values)
         }
     };
     const bf16_t* ximg;
@@ -131,13 +143,13 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
         const unsigned long long addr = a_goff[it] >= 0 ? in_addr : (unsigned long long)p.zeros;
         if (!(PROF && (p.dbg_skip & 2)))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
-                (__attribute__((address_space(3))) void*)(smem + tgt + (wave * 64 + 256 * it) * 16), 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(smem + tgt + (wave * 64 + NTHR * it) * 16), 16, 0, 0);
     };
     auto dma_w = [&](int it, const bf16_t* wsrc, int tgt) {
-        const int i = tid + 256 * it;
-        if ((R_W_ITEMS % 256 == 0 || (it + 1) * 256 <= R_W_ITEMS || wave < (R_W_ITEMS % 256) / 64) && !(PROF && (p.dbg_skip & 1)))
+        const int i = tid + NTHR * it;
+        if ((R_W_ITEMS % NTHR == 0 || (it + 1) * NTHR <= R_W_ITEMS || wave < (R_W_ITEMS % NTHR) / 64) && !(PROF && (p.dbg_skip & 1)))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (i ^ ((i >> 4) & 1)) * 8),   // the two slices of a row swapped for rows 8..15 (mod 16)
-                (__attribute__((address_space(3))) void*)(smem + R_A_BYTES + tgt + (wave * 64 + 256 * it) * 16), 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(smem + R_A_BYTES + tgt + (wave * 64 + NTHR * it) * 16), 16, 0, 0);
     };
     static_assert(R_W_ITEMS % 64 == 0, "weight pieces split on wave boundaries");
     // the k-th of the R_AIT + R_WIT requests of a chunk: halo first (it may come from HBM), weights (L2) after
@@ -350,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {
                     uint4 nb = make_uint4(0, 0, 0, 0);
-                    if (wave < 3) nb = *reinterpret_cast<const uint4*>(exch + wave * 4096 + ((nt * 2 + gp) * 64 + lane) * 16);
+                    if (wave < NWV - 1) nb = *reinterpret_cast<const uint4*>(exch + wave * 4096 + ((nt * 2 + gp) * 64 + lane) * 16);
                     const uint4 top = mx4(mx4(pk[0][nt][gp], pk[1][nt][gp]), pk[2][nt][gp]);
                     const uint4 bot = mx4(mx4(pk[2][nt][gp], pk[3][nt][gp]), nb);
                     pk[0][nt][gp] = make_uint4(hmax(top.x), hmax(top.y), hmax(top.z), hmax(top.w));
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(const ConvParams p, c
         }
     };
 
-    for (int i = tid; i < p.Cout; i += 256) reinterpret_cast<float*>(smem + 2 * R_BUF)[i] = p.bias[i];
+    for (int i = tid; i < p.Cout; i += NTHR) reinterpret_cast<float*>(smem + 2 * R_BUF)[i] = p.bias[i];
     cur = decode(lid);
     RingTile nxt = cur;
     describe(cur, 0); rebase(cur, 0);
@@ -455,17 +467,38 @@ bool conv_ring_supported(const ConvKernelCfg& cfg, const ConvParams& p) {
 }
 
 // orientation: -1 = whichever pads less (ties: lanes along the image rows), 0 / 1 forced (tests)
-bool conv_ring_transposed(const ConvParams& p, int orientation) {
+static bool ring_transposed_th(const ConvParams& p, int orientation, int th) {
     if (p.out_mode == OUT_POOL) return false;   // the pooled variant is built for one orientation
-    auto padded = [&](int lh, int lw) { return (long long)ceil_div(lh, R_TH) * R_TH * ceil_div(lw, R_TW) * R_TW; };
+    auto padded = [&](int lh, int lw) { return (long long)ceil_div(lh, th) * th * ceil_div(lw, R_TW) * R_TW; };
     return orientation < 0 ? padded(p.W, p.H) < padded(p.H, p.W) : orientation != 0;
+}
+// Does this launch take the 8-wave / 32-row tile?  The short-K layers do (Cin <= 64: four chunks per tile — stage 0 gains 11-14 %,
+// same-device A/B; with >= 128 input channels the 4-wave kernel's two independent work-groups per CU win by 0-6 %), where the
+// taller tile pads at most 5 % more pixels.  LUMINA_RING_NW8=0 / 2: never / whenever the padding allows (developer A/B).
+static bool ring_use_nw8(const ConvParams& p, int orientation) {
+    static const int mode = getenv("LUMINA_RING_NW8") ? atoi(getenv("LUMINA_RING_NW8")) : 1;
+    if (mode == 0 || p.out_mode != OUT_NORMAL || (mode == 1 && p.Cin > 64)) return false;   // (the pooled stem.conv3 measured the same on either tile: it stays on the 4-wave one)
+    auto padded = [&](bool tr, int th) { const int lh = tr ? p.W : p.H, lw = tr ? p.H : p.W; return (double)ceil_div(lh, th) * th * ceil_div(lw, R_TW) * R_TW; };
+    const double p4 = padded(ring_transposed_th(p, orientation, R_TH), R_TH), p8 = padded(ring_transposed_th(p, orientation, 2 * R_TH), 2 * R_TH);
+    return p8 <= 1.05 * p4;
+}
+bool conv_ring_transposed(const ConvParams& p, int orientation) {
+    return ring_transposed_th(p, orientation, ring_use_nw8(p, orientation) ? 2 * R_TH : R_TH);
+}
+// the instantiation a launch resolves to, spelled like the profiler spells it (minus blanks)
+const char* conv_ring_kernel_name(const ConvParams& p, int orientation) {
+    if (p.out_mode == OUT_POOL) return "conv_ring_kernel<0,false,true,4>";
+    const bool tr = conv_ring_transposed(p, orientation);
+    if (ring_use_nw8(p, orientation)) return tr ? "conv_ring_kernel<1,false,false,8>" : "conv_ring_kernel<0,false,false,8>";
+    return tr ? "conv_ring_kernel<1,false,false,4>" : "conv_ring_kernel<0,false,false,4>";
 }
 
 hipError_t conv_ring_launch(ConvParams p, int orientation, hipStream_t stream) {
     const bool tr = conv_ring_transposed(p, orientation);
     const int lh = tr ? p.W : p.H, lw = tr ? p.H : p.W;
     const bool pool = p.out_mode == OUT_POOL;
-    p.tiles_y = ceil_div(lh, R_TH); p.tiles_x = ceil_div(lw, R_TW); p.n_tiles = p.Cout / R_BN;
+    const bool nw8 = ring_use_nw8(p, orientation);
+    p.tiles_y = ceil_div(lh, nw8 ? 2 * R_TH : R_TH); p.tiles_x = ceil_div(lw, R_TW); p.n_tiles = p.Cout / R_BN;
     if (pool) { p.tiles_y = ceil_div((p.H - 1) / 2 + 1, (R_TH - 2) / 2); p.tiles_x = ceil_div((p.W - 1) / 2 + 1, (R_TW - 2) / 2); }
     const long long total = (long long)p.N * p.tiles_x * p.tiles_y * p.n_tiles;
     if (total <= 0 || total >= (1ll << 31)) return hipErrorInvalidValue;
@@ -478,6 +511,16 @@ hipError_t conv_ring_launch(ConvParams p, int orientation, hipStream_t stream) {
     static const bool prof = getenv("LUMINA_RING_PROF") != nullptr;
     static const int dbg = getenv("LUMINA_CONV_DBG") ? atoi(getenv("LUMINA_CONV_DBG")) : 0;
     p.dbg_skip = dbg;
+    if (nw8) {
+        const int wgs = per_xcd < 32 ? per_xcd : 32;   // one resident work-group per CU
+        constexpr int lds8 = RingCfg<8>::LDS;
+        const void* fn8 = tr ? reinterpret_cast<const void*>(conv_ring_kernel<1, false, false, 8>) : reinterpret_cast<const void*>(conv_ring_kernel<0, false, false, 8>);
+        { hipError_t e = locr_dyn_lds(fn8, lds8); if (e != hipSuccess) return e; }
+        unsigned long long* none8 = nullptr;
+        if (tr) hipLaunchKernelGGL((conv_ring_kernel<1, false, false, 8>), dim3(8 * wgs), dim3(512), lds8, stream, p, (int)total, per_xcd, wgs, none8);
+        else hipLaunchKernelGGL((conv_ring_kernel<0, false, false, 8>), dim3(8 * wgs), dim3(512), lds8, stream, p, (int)total, per_xcd, wgs, none8);
+        return hipGetLastError();
+    }
     if (prof && !pool) {   // developer tool: where do the waves' cycles go (synchronises, prints one line per launch)
         static unsigned long long* dprof = nullptr;
         if (!dprof && hipMalloc(&dprof, 64) != hipSuccess) return hipErrorOutOfMemory;

@@ -314,7 +314,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         eng->conv_bytes.push_back(2.0 * (in_elems + px * (out_mode == OUT_CONVT && p.fuse_w ? 4.0 : (double)L.cout) * (out_mode == OUT_UPSAMPLE ? (double)(1 << (2 * up_shift)) : (out_mode == OUT_POOL ? 0.25 : 1.0)) + (res ? px * (double)L.cout / (double)(1 << (2 * res_shift)) : 0.0) + (double)L.ks * L.ks * L.cin * L.cout));
         eng->conv_names.push_back(L.name);
         std::string kname = use_pw ? (L.cin == 64 ? "conv_pw_kernel<64>" : "conv_pw_kernel<128>") : conv_kernel_name(cfg);
-        if (use_ring) kname = out_mode == OUT_POOL ? "conv_ring_kernel<0,false,true>" : (conv_ring_transposed(p, eng->ring_orient) ? "conv_ring_kernel<1>" : "conv_ring_kernel<0>");
+        if (use_ring) kname = conv_ring_kernel_name(p, eng->ring_orient);
         if (out_mode == OUT_POOL && !use_ring) { const size_t pos = kname.rfind(",3,4>"); if (pos != std::string::npos) kname.replace(pos, 5, ",4,4>"); }  // the fused-pool instantiation
         eng->conv_kernels.push_back(kname);
     }

@@ -30,6 +30,7 @@ def test_config2_det_batch32_1024(engine, det_weights):
         engine.set_option("keep_taps", 0)
         engine.set_option("time_convs", 0)
     assert sum(k.startswith("conv_ring_kernel") for k in names) >= 2 * 10, names   # the ring kernel is what runs at this size
+    assert any(k.startswith("conv_ring_kernel") and k.endswith(",8>") for k in names), names   # ... its 8-wave tile on the 64-channel stage
     assert prob.shape == (32, 1024, 1024)
     bits = prob.view(torch.int16)
     for r in range(1, 8):                                                  # a page's result cannot depend on its batch slot
