@@ -129,9 +129,13 @@ def main():
     ap.add_argument("--deskew", action="store_true", help="also run the reference's default-on de-skew step (OpenCV there; off here: see config.deskew)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal, only with --dry-engine")
     ap.add_argument("--dry-engine", action="store_true", help="no GPU, fake recogniser outputs: rehearses launcher + gather on CPU")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal on a one-GPU box: every rank runs the real engine on cuda:0 and the "
+                    "gather goes through gloo (RCCL refuses two ranks on one device); the line says so, it is not a scaling number")
     args = ap.parse_args()
-    if args.backend == "gloo" and not args.dry_engine:
-        ap.error("--backend gloo is the CPU rehearsal of the multi-rank path and needs --dry-engine (the engine has no CPU path)")
+    if args.share_device:
+        args.backend = "gloo"
+    if args.backend == "gloo" and not (args.dry_engine or args.share_device):
+        ap.error("--backend gloo is the rehearsal of the multi-rank path and needs --dry-engine (CPU) or --share-device (one GPU)")
 
     # N > 1 without a launcher: become the launcher (before anything touches the GPU)
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -143,7 +147,7 @@ def main():
     from lumina_ocr.dist import PageGather
 
     rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d: reporting n_gpus=%d (the ranks that actually ran)" % (args.gpus, world, world), file=sys.stderr)
@@ -154,7 +158,7 @@ def main():
         torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if dry:
+        if dry or args.share_device:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=device)
@@ -229,7 +233,7 @@ def main():
             "config": {"workload": "end-to-end det+rec, batch=64 A4@200DPI pages per GPU (BASELINE configs[3])",
                        "pages_per_gpu": args.pages, "global_batch": args.pages * world, "page_px": [A4_H, A4_W],
                        "det_input_px": [hp, wp], "lines_last_step": n_lines, "pages_gathered_last_step": n_pages_last,
-                       "parallelism": "pages sharded dp%d, 1 all-gather/step" % world,
+                       "parallelism": "pages sharded dp%d, 1 all-gather/step" % world + (" (REHEARSAL: all ranks share cuda:0, gather over gloo — not a scaling number)" if args.share_device else ""),
                        "ranks": ranks_seen, "collective_backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if distributed else None,
                        "input": "pages pre-decoded (uint8 RGB) and resident in HBM when the timed region starts",
                        "outside_timed_region": "image decode, host->device copy, JPEG hand-off of the processed page (2.5 ms per 64 pages on the device)",
