@@ -287,7 +287,9 @@ __global__ __launch_bounds__(64 * MA_W) void svtr_attn_kernel(const uint16_t* qk
     for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const typename NM::frag_t*>(base + (size_t)qt * 3 * C + hd * AT_HD + ks * 16 + h * 8);
     __syncthreads();
     if (local ? (y0 >= gh) : (tile * 32 >= T)) return;
-    const float scale = 0.17677669529663687f;   // 32^-0.5
+    // scores are kept in the log2 domain (32^-0.5 * log2 e folded into one factor): exp(s - m) = exp2(s' - m') is ONE v_exp_f32 instead of
+    // libm's expf (range reduction + polynomial, ~20 instructions) — 17 of them per key tile and lane made the kernel transcendental-bound
+    const float scale = 0.17677669529663687f * 1.4426950408889634f;
     float m = -3.0e38f, l = 0.f;
     f32x16_t o;
 #pragma unroll
@@ -320,12 +322,12 @@ __global__ __launch_bounds__(64 * MA_W) void svtr_attn_kernel(const uint16_t* qk
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float mn = fmaxf(m, tmax);
-        const float corr = expf(m - mn);     // (both -3e38 before the first valid key: exp(0) = 1 scales zeros)
+        const float corr = __builtin_amdgcn_exp2f(m - mn);     // (both -3e38 before the first valid key: exp2(0) = 1 scales zeros)
         float psum = 0.f;
         uint32_t pk[8];
 #pragma unroll
         for (int j = 0; j < 16; j += 2) {
-            const float p0 = sc[j] > -1.0e38f ? expf(sc[j] - mn) : 0.f, p1 = sc[j + 1] > -1.0e38f ? expf(sc[j + 1] - mn) : 0.f;
+            const float p0 = sc[j] > -1.0e38f ? __builtin_amdgcn_exp2f(sc[j] - mn) : 0.f, p1 = sc[j + 1] > -1.0e38f ? __builtin_amdgcn_exp2f(sc[j + 1] - mn) : 0.f;
             psum += p0 + p1;
             pk[j >> 1] = NM::pack(p0, p1);
         }
