@@ -27,13 +27,25 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// erf to 1.5e-7 absolute (Abramowitz & Stegun 7.1.26): a reciprocal, a 5-term Horner polynomial and one v_exp_f32 — 14 instructions
+// against ~35 of libm's erff.  The GELU it feeds is rounded to a 16-bit tensor right after (8 or 11 mantissa bits): the definition's
+// exact-erf GELU (oracle/nets.py) and this one agree except on rounding ties.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float e = 1.f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    return copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + fast_erf(v * 0.70710678118654752f)); }
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.f);
         case ACT_HSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);  // x * relu6(x + 3) * fp32(1/6), no division
         case ACT_HSIGMOID: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
         case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // exact (erf) GELU
+        case ACT_GELU: return gelu_erf(v);  // erf GELU (fast_erf above)
         default: return v;
     }
 }

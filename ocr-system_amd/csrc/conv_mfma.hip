@@ -319,7 +319,7 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
     else if (p.act == ACT_HSWISH) { FOR_ALL_ACC(v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f)) }
     else if (p.act == ACT_SIGMOID) { FOR_ALL_ACC(1.f / (1.f + expf(-v))) }
     else if (p.act == ACT_HSIGMOID) { FOR_ALL_ACC(fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f)) }
-    else if (p.act == ACT_GELU) { FOR_ALL_ACC(0.5f * v * (1.f + erff(v * 0.70710678118654752f))) }
+    else if (p.act == ACT_GELU) { FOR_ALL_ACC(gelu_erf(v)) }
 #undef FOR_ALL_ACC
     if constexpr (KS == 3) {
         if (direct) {

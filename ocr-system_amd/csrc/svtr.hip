@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, (GCfg<NT, BK>::LDS <= 80 * 1024 && NT <= 6 ? 2
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float y = v[j];
-                if (p.act == ACT_GELU) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752f));
+                if (p.act == ACT_GELU) y = gelu_erf(y);
                 else if (p.act == ACT_HSWISH) y = y * fminf(fmaxf(y + 3.f, 0.f), 6.f) * (1.f / 6.f);
                 if (rrow && p.res_post) y = NM::one(NM::cvt(y)) + rv4[j];   // the activation's output is a stored (rounded) tensor of the definition
                 if constexpr (LN) { y = NM::one(NM::cvt(y)); rsum += y; }   // the (un-stored) linear output is a 16-bit tensor in the definition
