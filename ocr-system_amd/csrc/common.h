@@ -37,6 +37,9 @@ __device__ __forceinline__ float fast_erf(float x) {
     const float e = 1.f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
     return copysignf(e, x);
 }
+// sigmoid as v_exp_f32 + v_rcp_f32 (each ~1 ulp) instead of libm expf + an IEEE division (~30 instructions per value); its only user,
+// the probability map, is rounded to bf16
+__device__ __forceinline__ float fast_sigmoidf(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + fast_erf(v * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -44,7 +47,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case ACT_RELU: return fmaxf(v, 0.f);
         case ACT_HSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);  // x * relu6(x + 3) * fp32(1/6), no division
         case ACT_HSIGMOID: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
-        case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case ACT_SIGMOID: return fast_sigmoidf(v);
         case ACT_GELU: return gelu_erf(v);  // erf GELU (fast_erf above)
         default: return v;
     }

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
             _Pragma("unroll") for (int j = 0; j < 16; ++j) { const float v = acc[mt][nt][j]; acc[mt][nt][j] = (expr); }
     if (p.act == ACT_RELU) { FOR_ALL_ACC(fmaxf(v, 0.f)) }
     else if (p.act == ACT_HSWISH) { FOR_ALL_ACC(v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f)) }
-    else if (p.act == ACT_SIGMOID) { FOR_ALL_ACC(1.f / (1.f + expf(-v))) }
+    else if (p.act == ACT_SIGMOID) { FOR_ALL_ACC(fast_sigmoidf(v)) }
     else if (p.act == ACT_HSIGMOID) { FOR_ALL_ACC(fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f)) }
     else if (p.act == ACT_GELU) { FOR_ALL_ACC(gelu_erf(v)) }
 #undef FOR_ALL_ACC
