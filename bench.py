@@ -65,13 +65,29 @@ def cpu_baseline(det_w, rec_w, charset, n_pages=6):
                       % (n_pages, sum(len(o["texts"]) for o in out), dt)}
 
 
+def visible_gpus() -> int:
+    """Device count as a CHILD process sees it (the launcher itself never imports torch or touches the GPU)."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` with no RANK in the environment: this process becomes the launcher.  It never touches the GPU
     (no torch.cuda call, not even an import of torch): it starts N fresh child processes of this file, one rank per GPU, with
-    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, waits for them and exits non-zero if any of them did.
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, polls them and exits non-zero if any of them did — the
+    first failing rank ends the others (they would otherwise sit in a collective waiting for it).
     Rank 0 inherits stdout and prints the one JSON line.  (Under `python -m torch.distributed.run` RANK is set and this is skipped.)"""
     import socket
     import subprocess
+    if not args.dry_engine:      # one clear message instead of N torch tracebacks on a mis-sized node
+        need, have = (1 if args.share_device else args.gpus), visible_gpus()
+        if have < need:
+            print("bench.py: --gpus %d needs %d visible GPU(s), this node shows %d: nothing was started" % (args.gpus, need, have), file=sys.stderr)
+            return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -82,12 +98,30 @@ def launch_ranks(args) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for r, p in enumerate(procs):
-        c = p.wait()
-        if c != 0:
-            print("bench.py: rank %d exited with code %d" % (r, c), file=sys.stderr)
-            rc = rc or (c if c > 0 else 1)
+    rc, live = 0, dict(enumerate(procs))
+    while live:
+        for r, p in list(live.items()):
+            c = p.poll()
+            if c is None:
+                continue
+            del live[r]
+            if c != 0:
+                print("bench.py: rank %d exited with code %d" % (r, c), file=sys.stderr)
+                rc = rc or (c if c > 0 else 1)
+        if rc and live:          # a rank died: the survivors are blocked in init / all_reduce / barrier — end them (our own children, by PID)
+            for p in live.values():
+                p.terminate()
+            deadline = time.time() + 10.0
+            for r, p in live.items():
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+                print("bench.py: rank %d stopped after another rank failed" % r, file=sys.stderr)
+            live = {}
+        elif live:
+            time.sleep(0.05)
     return rc
 
 
@@ -129,6 +163,8 @@ def main():
     ap.add_argument("--deskew", action="store_true", help="also run the reference's default-on de-skew step (OpenCV there; off here: see config.deskew)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal, only with --dry-engine")
     ap.add_argument("--dry-engine", action="store_true", help="no GPU, fake recogniser outputs: rehearses launcher + gather on CPU")
+    ap.add_argument("--seed-rank", type=int, default=-1, help="(tests) generate the pages of THIS rank (page seed = 2024 + 1000 * rank) whatever RANK says")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="(launcher test, --dry-engine only) this rank raises after the process group is up")
     ap.add_argument("--share-device", action="store_true", help="rehearsal on a one-GPU box: every rank runs the real engine on cuda:0 and the "
                     "gather goes through gloo (RCCL refuses two ranks on one device); the line says so, it is not a scaling number")
     args = ap.parse_args()
@@ -163,6 +199,8 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=device)
     ranks_seen = dist.get_world_size() if distributed else 1
+    if dry and args.fail_rank == rank:
+        raise RuntimeError("rank %d fails on request (--fail-rank)" % rank)
 
     charset = arch.ctc_charset()
     side = torch.cuda.Stream(device) if (distributed and not dry) else None   # result gather runs beside the next step's detection kernels
@@ -179,7 +217,7 @@ def main():
         eng.load_rec(rec_w)
         eng.set_option("det_sub_batch", args.det_sub_batch)
         pipe = OcrPipeline(eng, charset=charset, post=arch.TEXT_PATH_POST, gather=gather)
-        pages = make_pages(torch, args.pages, 2024 + 1000 * rank, device)
+        pages = make_pages(torch, args.pages, 2024 + 1000 * (args.seed_rank if args.seed_rank >= 0 else rank), device)
 
     def run_steps(k):
         """k steps through run_many: step i's host-side string decode (multi-GPU: its result gather, on a side stream) overlaps
@@ -209,6 +247,12 @@ def main():
         elapsed = float(t.item())
     n_lines = int(dets.counts.sum()) if hasattr(dets, "counts") else sum(len(d.texts) for d in dets)
     n_pages_last = len(dets)
+    # identity of the gathered pages (small runs only: the multi-rank tests compare it with each rank's pages run alone)
+    digests = None
+    if n_pages_last <= 16:
+        import zlib
+        per_page = [pg["texts"] for pg in dets.pages()] if hasattr(dets, "pages") else [list(d.texts) for d in dets]
+        digests = ["%08x" % zlib.crc32("\n".join(t).encode("utf-8")) for t in per_page]
 
     roofline = None
     if not dry:
@@ -232,7 +276,7 @@ def main():
             "data": "synthetic (rendered text pages + noise, seeded); weights random-init (seeded), no checkpoints offline",
             "config": {"workload": "end-to-end det+rec, batch=64 A4@200DPI pages per GPU (BASELINE configs[3])",
                        "pages_per_gpu": args.pages, "global_batch": args.pages * world, "page_px": [A4_H, A4_W],
-                       "det_input_px": [hp, wp], "lines_last_step": n_lines, "pages_gathered_last_step": n_pages_last,
+                       "det_input_px": [hp, wp], "lines_last_step": n_lines, "pages_gathered_last_step": n_pages_last, "page_digests_last_step": digests,
                        "parallelism": "pages sharded dp%d, 1 all-gather/step" % world + (" (REHEARSAL: all ranks share cuda:0, gather over gloo — not a scaling number)" if args.share_device else ""),
                        "ranks": ranks_seen, "collective_backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if distributed else None,
                        "input": "pages pre-decoded (uint8 RGB) and resident in HBM when the timed region starts",
@@ -254,6 +298,11 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def flat_kernel_name(name):
+    """the profiler's spelling of a kernel name -> the engine's (no blanks)"""
+    return name.replace(" ", "")
 
 
 def _sha16(path):
@@ -285,10 +334,9 @@ def measure_roofline(eng, pipe, pages):
         if srcs and cur == srcs:
             want = dom.replace(" ", "")
             for name, v in pmc["kernels"].items():
-                flat = name.replace(" ", "").replace(",false,false>", ">")
-                if want in flat:
+                if want in flat_kernel_name(name):
                     traffic = v.get("hbm_bytes_per_launch")
-                    note = "mean HBM bytes/launch of this kernel in a 16-page det forward (profiles/%s); bench launches cover 16-page sub-batches too" % PMC_FILE
+                    note = "mean HBM bytes/launch of this kernel over two %d-page det forwards, the bench's launch size (tools/pmc_target.py; profiles/%s): 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes" % (PAGES_PER_RANK, PMC_FILE)
         else:
             note = "profiles/%s was collected on other kernel sources than the ones running: not reported" % PMC_FILE
     except Exception:

@@ -15,7 +15,9 @@
  *     tensor.data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream).
  *     Work is enqueued asynchronously on that stream unless stated otherwise.
  *   - a handle is bound to one device and must not be used from two threads at once (the
- *     reference serialises pages with a Semaphore(1): ocr_service.py:157, :404).
+ *     reference serialises pages with a Semaphore(1): ocr_service.py:157, :404).  Every entry
+ *     runs with the handle's device current and puts the calling thread's previous device back
+ *     before it returns.
  *   - images are uint8 HWC RGB; activations are bf16 NHWC; the probability map is bf16.
  */
 #ifndef LUMINA_OCR_H

@@ -19,13 +19,27 @@
     catch (...) { return locr_fail(h, "exception", "unknown"); }
 
 // every entry that allocates, copies or launches binds the calling thread to the handle's device first: provider threads
-// (asyncio.to_thread workers) start on device 0 whatever device the handle was created on
+// (asyncio.to_thread workers) start on device 0 whatever device the handle was created on.  The thread's previous device is put
+// back when the entry returns (a host that keeps its own current device — torch without an explicit device, a second engine on
+// another GPU — is not silently rebound).
+namespace {
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        err = hipSetDevice(dev);
+        if (prev == dev) prev = -1;   // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+}  // namespace
 #define BIND(h)                                                                                              \
-    do {                                                                                                     \
-        if (!(h)) return 1;                                                                                  \
-        hipError_t _be = hipSetDevice((h)->device);                                                          \
-        if (_be != hipSuccess) return locr_fail((h), "hipSetDevice", hipGetErrorString(_be));                \
-    } while (0)
+    if (!(h)) return 1;                                                                                      \
+    DeviceGuard _device_guard((h)->device);                                                                  \
+    if (_device_guard.err != hipSuccess) return locr_fail((h), "hipSetDevice", hipGetErrorString(_device_guard.err))
 
 extern "C" {
 

@@ -42,7 +42,11 @@ def test_bench_gpus_1_stays_single_process():
 
 def test_bench_under_an_external_launcher_uses_its_ranks():
     """torchrun-style: RANK/WORLD_SIZE in the environment -> no second launcher, the process is a rank."""
-    r = _run(["--gpus", "1"], env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29877"))
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = _run(["--gpus", "1"], env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["config"]["collective_backend"] == "gloo"
@@ -51,3 +55,26 @@ def test_bench_under_an_external_launcher_uses_its_ranks():
 def test_launcher_propagates_a_failing_rank():
     r = _run(["--gpus", "2", "--pages", "-3"])             # every rank raises (negative shard size)
     assert r.returncode != 0
+
+
+def test_launcher_ends_the_survivors_when_one_rank_dies():
+    """Only rank 1 raises; rank 0 is then blocked in its first collective (gloo would wait forever): the launcher must notice,
+    stop rank 0 and return non-zero well inside the timeout."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--fail-rank", "1"])
+    assert r.returncode != 0
+    assert "rank 1 exited" in r.stderr and time.time() - t0 < 120
+
+
+def test_launcher_preflight_refuses_a_node_with_too_few_gpus():
+    """No GPU in the CPU container: `--gpus 2` with the real engine must stop with ONE message before any rank starts."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this node has the GPUs")
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 2 and "visible GPU" in r.stderr and "Traceback" not in r.stderr

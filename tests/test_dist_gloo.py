@@ -62,10 +62,14 @@ def _worker(rank, world, port, n_pages, q):
 
 def test_two_rank_gather_reassembles_all_pages_in_order():
     """7 pages over 2 ranks (4 + 3): the short rank's padding page must not show up — page p of the result is global page p."""
+    import socket
     world, n_pages = 2, 7
+    with socket.socket() as s:                         # a free port, not a fixed one: concurrent runs must not collide
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, 29731, n_pages, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pages, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]
