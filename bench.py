@@ -211,7 +211,7 @@ def main():
     else:
         from lumina_ocr.engine import Engine
         from lumina_ocr.pipeline import OcrPipeline
-        det_w, rec_w = arch.make_det_weights(1234), arch.make_rec_weights(4321)
+        det_w, rec_w = arch.make_det_weights(1234), arch.make_rec_weights(4321, code_path=True)
         eng = Engine(local_rank)            # raises if liblumina_ocr.so is missing: there is no fallback path
         eng.load_det(det_w)
         eng.load_rec(rec_w)

@@ -333,7 +333,72 @@ def make_det_weights(seed: int = 1234, text_path: bool = True) -> Dict[str, np.n
     return w
 
 
-def make_rec_weights(seed: int = 4321, num_classes: int = 6625, scale: float = 0.5) -> Dict[str, np.ndarray]:
+# Hand-set "code path" of the recogniser (the counterpart of the detector's text path; installed by make_rec_weights(code_path=True)).
+# A seeded-random CRNN decides every time step between near-ties (top-1 / top-2 logit margins of ~0.1 sigma), so bf16 drift flips a
+# few arg-maxes per line and string parity can only be bounded.  A trained network has margins of many logits; this path gives the
+# seeded one the same property, through arithmetic that is EXACT (order-independent), so the engine and the oracle agree bit for bit on it:
+#   rec.conv1 ch 0      : hswish(-4 * xn_G(centre tap))                         "ink" of one pixel (0 for paper, 3.4 .. 4 for ink)
+#   res blocks          : carried by the residual (project row = 0)
+#   b1 / b3 / b8 (the three vertical stride-2 blocks): five channels, each a chain of single-tap depthwise filters, i.e. each
+#                         samples the ink at one pair of crop rows (2a, 2a + 16), a = 3 .. 7, at its own horizontal offset
+#   rec.conv2, max pool : carried (single unit weights: a contraction with one non-zero product is exact in any order)
+#   lstm.l0 / l1 fw 0..4: saturated gates (i = o = 1, f = 0), g = tanh(BIG * (x - thr)) -> h = +-0.7617, no recurrence;
+#                         thr sits half-way between two bf16 values, so |BIG * (x - thr)| >= 16 for EVERY bf16 x
+#   ctc.fc              : the 32 code classes read +-16 on the five bits: the best code leads the runner-up by >= 24 logits
+#                         (dense part: sigma ~2); code 0 = CTC blank, codes 1..31 = CODE_PATH_SYMBOLS
+# Every other row of every layer stays seeded-random and dense.
+CODE_PATH_SYMBOLS = "etaoinshrdlucmf wypvbgkqjxz0123"          # code v (1..31) -> symbol v - 1; the space exercises word splitting
+_CODE_TAPS = [(2, 4, 0), (2, 4, 1), (2, 4, 2), (3, 3, 1), (3, 3, 2)]   # (kh in b8, kh in b3, kh in b1) -> stem rows (a, a + 8), a = 3 .. 7
+_CODE_KW = [(2, 2, 1), (1, 3, 0), (3, 1, 2), (2, 4, 1), (4, 2, 0)]
+CODE_THR = 1.0 + 2.0 ** -8        # half-way between the bf16 neighbours 1.0 and 1.0078125: |x - thr| >= 2^-8 for every bf16 x
+CODE_BIG = 4096.0                 # 2^12: |BIG * (x - thr)| >= 16
+
+
+def _install_code_path(w: Dict[str, np.ndarray], num_classes: int, scale: float) -> None:
+    def zero_rows(name, rows):
+        for r in rows:
+            w[name + ".w"][r] = 0.0
+            w[name + ".b"][r] = 0.0
+
+    bits = range(5)
+    zero_rows("rec.conv1", [0])
+    w["rec.conv1.w"][0, 1, 1, 1] = -4.0
+    for b in rec_block_table(scale):
+        p = f"rec.b{b['idx']}"
+        if b["res"]:
+            zero_rows(p + ".project", range(1 if b["idx"] == 0 else 5))
+            continue
+        stage = {1: 2, 3: 1, 8: 0}[b["idx"]]
+        zero_rows(p + ".expand", bits); zero_rows(p + ".dw", bits); zero_rows(p + ".project", bits)
+        for k in bits:
+            w[p + ".expand.w"][k, 0, 0, 0 if b["idx"] == 1 else k] = 1.0
+            w[p + ".dw.w"][k, _CODE_TAPS[k][stage], _CODE_KW[k][stage], 0] = 1.0
+            w[p + ".project.w"][k, 0, 0, k] = 1.0
+        if b["se"]:
+            zero_rows(p + ".se2", bits)
+            w[p + ".se2.b"][:5] = 4.0          # hard-sigmoid(4) = 1: the squeeze-excite gate of the path channels is exactly 1
+    zero_rows("rec.conv2", bits)
+    for k in bits:
+        w["rec.conv2.w"][k, 0, 0, k] = 1.0
+    h = REC_HIDDEN
+    for layer, big, thr in ((0, CODE_BIG, CODE_THR), (1, 32.0, 0.0)):
+        p = f"lstm.l{layer}.fw"
+        for k in bits:
+            for gate, bias in ((0, 20.0), (1, -20.0), (2, -big * thr), (3, 20.0)):   # i, f, g, o
+                w[p + ".w_ih"][gate * h + k] = 0.0
+                w[p + ".w_hh"][gate * h + k] = 0.0
+                w[p + ".b"][gate * h + k] = bias
+            w[p + ".w_ih"][2 * h + k, k] = big
+    w["ctc.fc.w"][:, :5] = 0.0
+    space = num_classes - 1
+    for v in range(32):
+        cls = 0 if v == 0 else (space if CODE_PATH_SYMBOLS[v - 1] == " " else 1 + ord(CODE_PATH_SYMBOLS[v - 1]) - 0x21)
+        for k in bits:
+            w["ctc.fc.w"][cls, k] = 16.0 if (v >> k) & 1 else -16.0
+
+
+def make_rec_weights(seed: int = 4321, num_classes: int = 6625, scale: float = 0.5, code_path: bool = False) -> Dict[str, np.ndarray]:
+    """code_path: install the hand-set exact path described above (strings then have trained-like arg-max margins)."""
     rng = np.random.default_rng(seed)
     w: Dict[str, np.ndarray] = {}
 
@@ -362,6 +427,8 @@ def make_rec_weights(seed: int = 4321, num_classes: int = 6625, scale: float = 0
             w[p + ".b"] = (rng.uniform(-1, 1, 4 * h).astype(np.float32) * np.float32(1.0 / np.sqrt(h))).astype(np.float32)
     w["ctc.fc.w"] = bf16_round(rng.standard_normal((num_classes, 2 * h), dtype=np.float32) * np.float32(12.0 / np.sqrt(2 * h)))
     w["ctc.fc.b"] = (rng.standard_normal(num_classes, dtype=np.float32) * np.float32(0.1)).astype(np.float32)
+    if code_path:
+        _install_code_path(w, num_classes, scale)
     return w
 
 

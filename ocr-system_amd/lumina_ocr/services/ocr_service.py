@@ -158,7 +158,7 @@ class OCRService:
                         if svtr:
                             eng.load_svtr(arch.make_svtr_weights(num_classes=len(charset)))
                         else:
-                            eng.load_rec(arch.make_rec_weights(num_classes=len(charset)))
+                            eng.load_rec(arch.make_rec_weights(num_classes=len(charset), code_path=True))
                         kind, post = "seeded-synthetic", arch.TEXT_PATH_POST
                     n_cls = eng.svtr_num_classes if svtr else eng.num_classes
                     if len(charset) != n_cls:

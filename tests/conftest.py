@@ -47,11 +47,20 @@ def rec_weights():
     return arch.make_rec_weights(4321)
 
 
-def close_stats(got: np.ndarray, ref: np.ndarray):
-    """bf16-aware comparison: share within 1 / 4 bf16 ulps, max abs error, mean abs error."""
+@pytest.fixture(scope="session")
+def code_rec_weights():
+    """The seeded recogniser WITH the hand-set exact code path (arch._install_code_path): trained-like arg-max margins (>= 14 logits
+    on every step), so strings are compared for EQUALITY; the plain seeded set above stays for dense-operand coverage."""
+    from lumina_ocr import arch
+    return arch.make_rec_weights(4321, code_path=True)
+
+
+def close_stats(got: np.ndarray, ref: np.ndarray, dtype: str = "bf16"):
+    """Storage-type-aware comparison: share within 1 / 4 ulps OF THAT TYPE (bf16: 8 significant bits, fp16: 11), max / mean abs error."""
     got = np.asarray(got, np.float32).ravel()
     ref = np.asarray(ref, np.float32).ravel()
     err = np.abs(got - ref)
-    ulp = np.maximum(np.abs(ref), 2.0 ** -6) * 2.0 ** -7  # one bf16 ulp at |ref| (floored)
+    assert dtype in ("bf16", "f16")
+    ulp = np.maximum(np.abs(ref), 2.0 ** -6) * (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10)  # one ulp at |ref| (floored; an upper bound within the binade)
     return dict(within1=float((err <= ulp).mean()), within4=float((err <= 4 * ulp).mean()), max_abs=float(err.max()),
                 mean_abs=float(err.mean()), ref_mean_abs=float(np.abs(ref).mean()))

@@ -66,12 +66,35 @@ def test_config3_rec_batch512(engine, rec_weights):
         assert torch.equal(idx[:64], idx[64 * r:64 * r + 64])
     ridx, rprob, _, _ = nets.rec_forward(rec_weights, base[:8])
     agree = float((idx[:8].cpu().numpy() == ridx).mean())
-    assert agree > 0.8, agree
+    assert agree > 0.9, agree
     ref = nets.ctc_greedy(idx[:8].cpu().numpy(), prob[:8].cpu().numpy(), arch.ctc_charset())   # decode is exact on the same ids
     cs = arch.ctc_charset()
     for i in range(8):
         got = "".join(cs[k] for k in text[i, : int(length[i])].cpu().tolist())
         assert got == ref[i][0] and np.float32(score[i].item()) == np.float32(ref[i][1])
+
+
+def test_config3_rec_batch512_strings_equal_the_oracle(engine, code_rec_weights):
+    """The same configuration with the code-path weight set (trained-like margins): per-crop STRING EQUALITY with the oracle
+    on all 64 distinct crops of the batch of 512, in ragged sub-batches."""
+    from oracle import nets
+    rng = np.random.default_rng(8642)
+    base = np.stack([synth.synth_crop(rng)[0] for _ in range(64)])
+    crops = torch.from_numpy(np.concatenate([base] * 8)).cuda()
+    engine.load_rec(code_rec_weights)
+    engine.set_option("rec_sub_batch", 200)
+    idx, prob = engine.rec_forward(crops)
+    text, length, score = engine.ctc_decode(idx, prob)
+    torch.cuda.synchronize()
+    engine.set_option("rec_sub_batch", 2048)
+    ridx, rprob, logits, _ = nets.rec_forward(code_rec_weights, base)
+    top2 = np.partition(logits, -2, axis=2)[:, :, -2:]
+    assert (top2[:, :, 1] - top2[:, :, 0]).min() > 8.0
+    cs = arch.ctc_charset()
+    ref = [r[0] for r in nets.ctc_greedy(ridx, rprob, cs)]
+    got = arch.TextDecoder(cs).decode(text.cpu().numpy(), length.cpu().numpy())
+    assert got == ref * 8
+    assert np.array_equal(idx.cpu().numpy(), np.concatenate([ridx] * 8))
 
 
 def test_config4_end_to_end_a4_pages_and_detector_recall(engine, det_weights, rec_weights):
@@ -131,8 +154,8 @@ def test_config5_svtr_base_fp16_batch512_with_a_dictionary_file(engine, tmp_path
     for name in ("svtr.b2", "svtr.b8", "svtr.b17", "svtr.seq"):           # last block of each stage + the sequence (first 4 crops)
         got = engine.read_tap(name, "f16")
         got = got.reshape((got.shape[0], -1, got.shape[-1]))[:4]
-        st = close_stats(got, taps[name])
-        assert st["within4"] > 0.95 and st["mean_abs"] < 0.02 * max(st["ref_mean_abs"], 1e-3), (name, st)
+        st = close_stats(got, taps[name], "f16")                          # graded in fp16 ulps (2^-10 relative)
+        assert st["within4"] > 0.7 and st["mean_abs"] < 0.005 * max(st["ref_mean_abs"], 1e-3), (name, st)
     assert float((idx[:4].cpu().numpy() == ridx).mean()) > 0.97
     text, length, score = engine.ctc_decode(idx, prob)
     ref = nets.ctc_greedy(idx[:6].cpu().numpy(), prob[:6].cpu().numpy(), cs)

@@ -27,9 +27,10 @@ def _edit(a, b):
     return d[-1]
 
 
-def test_pipeline_matches_oracle_pipeline(engine, det_weights, rec_weights):
+def _compare_with_oracle(engine, det_weights, rec_weights, seeds):
+    """Pages through the HIP pipeline and through oracle/pipeline.py -> statistics of the comparison (boxes matched by IoU)."""
     from oracle import pipeline as op
-    pages = np.stack([synth.synth_page(700, 1000, 40 + i, n_lines=14)[0] for i in range(2)])
+    pages = np.stack([synth.synth_page(700, 1000, sd, n_lines=14)[0] for sd in seeds])
     engine.load_det(det_weights)
     engine.load_rec(rec_weights)
     pipe = OcrPipeline(engine, max_dimension=800, post=arch.TEXT_PATH_POST)   # exercises the LANCZOS path: 1000x700 -> 800x560
@@ -40,7 +41,7 @@ def test_pipeline_matches_oracle_pipeline(engine, det_weights, rec_weights):
     ious, eds, nchar = [], 0, 0
     # String parity, stated per time step: on the crops of the oracle's own boxes, every step whose oracle top-1 / top-2 logit
     # margin exceeds MARGIN_EPS (logit units, tests/test_gpu_rec.py) must give the same class id; a line whose 80 steps are all
-    # clear must give the identical string; the edit-distance bound below covers what is left (near-ties of the seeded network).
+    # clear must give the identical string.
     n_clear_steps = n_steps = n_clear_lines = 0
     cs = pipe.charset
     for pi, r in enumerate(ref):
@@ -58,7 +59,6 @@ def test_pipeline_matches_oracle_pipeline(engine, det_weights, rec_weights):
             n_clear_lines += 1
             got = "".join(cs[k] for k in gtext[li, : int(glen[li])].cpu().tolist())
             assert got == r["texts"][li], (pi, li, got, r["texts"][li])
-    assert n_clear_steps >= 10, (n_clear_steps, n_steps)
     for d, r in zip(dets, ref):
         n_ref += len(r["quads"])
         used = set()
@@ -78,18 +78,42 @@ def test_pipeline_matches_oracle_pipeline(engine, det_weights, rec_weights):
                 n_exact_text += int(t == d.texts[bi])
                 eds += _edit(t, d.texts[bi])
                 nchar += max(len(t), 1)
-    assert n_ref > 0 and n_match >= 0.9 * n_ref, (n_match, n_ref)
-    assert np.mean(np.array(ious) >= 0.99) >= 0.9 and np.min(ious) > 0.9, sorted(ious)[:5]
-    assert eds <= 0.2 * nchar, (eds, nchar)               # stated edit-distance bound for the seeded recogniser
+    return dict(ref_boxes=n_ref, boxes_found=sum(len(d.quads) for d in dets), matched=n_match, exact_boxes=n_exact_box, exact_texts=n_exact_text,
+                min_iou=float(np.min(ious)), mean_iou=float(np.mean(ious)), share_iou_099=float(np.mean(np.array(ious) >= 0.99)),
+                edit_distance=eds, chars=nchar, margin_eps=MARGIN_EPS, clear_step_share=n_clear_steps / max(n_steps, 1), clear_steps=n_clear_steps,
+                clear_step_agreement=1.0, fully_clear_lines=n_clear_lines, fully_clear_lines_exact=n_clear_lines)
+
+
+def _dump(name, st):
     try:
         import os
         os.makedirs("gpurun_out", exist_ok=True)
-        json.dump(dict(ref_boxes=n_ref, matched=n_match, exact_boxes=n_exact_box, exact_texts=n_exact_text, min_iou=float(np.min(ious)),
-                       mean_iou=float(np.mean(ious)), edit_distance=eds, chars=nchar, margin_eps=MARGIN_EPS,
-                       clear_step_share=n_clear_steps / max(n_steps, 1), clear_step_agreement=1.0, fully_clear_lines=n_clear_lines,
-                       fully_clear_lines_exact=n_clear_lines), open("gpurun_out/parity_e2e.json", "w"))
+        json.dump(st, open("gpurun_out/" + name, "w"))
     except OSError:
         pass
+
+
+def test_pipeline_equals_oracle_pipeline_boxes_and_strings(engine, det_weights, code_rec_weights):
+    """The parity statement of north_star as an EQUALITY: every box the oracle pipeline finds is found with identical integer
+    coordinates (IoU 1.0) and carries the identical string.  Weights: the detector's hand-set text path + the recogniser's hand-set
+    code path (trained-like margins: every one of the 80 steps of every line is clear), everything else seeded-random and dense."""
+    st = _compare_with_oracle(engine, det_weights, code_rec_weights, seeds=(40, 41, 42))
+    _dump("parity_e2e.json", st)
+    assert st["ref_boxes"] >= 30 and st["boxes_found"] == st["ref_boxes"] == st["matched"], st
+    assert st["exact_boxes"] == st["ref_boxes"] and st["min_iou"] == 1.0, st
+    assert st["exact_texts"] == st["ref_boxes"] and st["edit_distance"] == 0, st          # strings exact
+    assert st["clear_step_share"] == 1.0 and st["fully_clear_lines"] == st["ref_boxes"], st
+
+
+def test_pipeline_matches_oracle_pipeline_dense_recogniser(engine, det_weights, rec_weights):
+    """The same comparison with the plain seeded recogniser (every row dense, near-ties at most time steps): boxes as above;
+    strings within the stated edit distance, every clear step identical."""
+    st = _compare_with_oracle(engine, det_weights, rec_weights, seeds=(40, 41))
+    _dump("parity_e2e_dense_rec.json", st)
+    assert st["clear_steps"] >= 10, st
+    assert st["ref_boxes"] > 0 and st["matched"] >= 0.9 * st["ref_boxes"], st
+    assert st["share_iou_099"] >= 0.9 and st["min_iou"] > 0.9, st
+    assert st["edit_distance"] <= 0.08 * st["chars"], st      # stated edit-distance bound for near-tie logits (measured 4.6 %)
 
 
 def test_provider_end_to_end_schema(engine, tmp_path):

@@ -21,6 +21,10 @@ def _crops(n, seed):
     return np.stack([synth.synth_crop(rng)[0] for _ in range(n)])
 
 
+# share of a tap's values within 4 ulps of the storage type: (embedding + first two blocks, deeper taps)
+FP_LO4 = {"bf16": (0.97, 0.7), "f16": (0.97, 0.7)}
+
+
 @pytest.mark.parametrize("variant,dtype", [("tiny", "bf16"), ("tiny", "f16"), ("base", "bf16"), ("base", "f16")])
 def test_svtr_forward_taps(engine, variant, dtype):
     """Every tap of the model (patch embedding + positional embedding, all mixing blocks, both merging stages, the sequence) vs the
@@ -40,12 +44,13 @@ def test_svtr_forward_taps(engine, variant, dtype):
     stats = {}
     for name in ["svtr.embed"] + ["svtr.b%d" % i for i in range(nblocks)] + ["svtr.sub0", "svtr.sub1", "svtr.seq"]:
         got = engine.read_tap(name, dtype).reshape(taps[name].shape)
-        st = stats[name] = close_stats(got, taps[name])
-        # LayerNorm keeps magnitudes at O(1); one-ulp differences of fp32 summation order accumulate over the blocks.  "ulp" in
-        # close_stats is a bf16 ulp (2^-7 relative): fp16 storage (2^-10) must sit well inside it.
+        st = stats[name] = close_stats(got, taps[name], dtype)
+        # LayerNorm keeps magnitudes at O(1); one-ulp differences of fp32 summation order accumulate over the blocks.  The ulp is
+        # the STORAGE type's: 2^-7 relative for bf16, 2^-10 for fp16 (an fp16 tensor graded in bf16 ulps would pass 8x too easily).
         early = name in ("svtr.embed", "svtr.b0", "svtr.b1")
-        lo4 = (0.97 if early else 0.7) if dtype == "bf16" else (0.999 if early else 0.95)
-        assert st["within4"] > lo4 and st["mean_abs"] < (0.01 if early else 0.02) * max(st["ref_mean_abs"], 1e-3), (name, st)
+        lo4 = FP_LO4[dtype][0 if early else 1]
+        rel = (0.01 if early else 0.02) * (1.0 if dtype == "bf16" else 0.25)
+        assert st["within4"] > lo4 and st["mean_abs"] < rel * max(st["ref_mean_abs"], 1e-3), (name, st)
     engine.set_option("keep_taps", 0)
     try:
         import json, os
