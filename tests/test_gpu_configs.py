@@ -66,7 +66,7 @@ def test_config3_rec_batch512(engine, rec_weights):
         assert torch.equal(idx[:64], idx[64 * r:64 * r + 64])
     ridx, rprob, _, _ = nets.rec_forward(rec_weights, base[:8])
     agree = float((idx[:8].cpu().numpy() == ridx).mean())
-    assert agree > 0.9, agree
+    assert agree > 0.95, agree
     ref = nets.ctc_greedy(idx[:8].cpu().numpy(), prob[:8].cpu().numpy(), arch.ctc_charset())   # decode is exact on the same ids
     cs = arch.ctc_charset()
     for i in range(8):

@@ -9,7 +9,7 @@ from lumina_ocr import arch, synth
 pytestmark = pytest.mark.gpu
 
 MARGIN_EPS = 1.0   # logit units; see test_rec_forward_taps
-AGREE_MIN = 0.9    # arg-max agreement of the plain seeded set (near-ties at most steps); the code-path set below is held to EQUALITY
+AGREE_MIN = 0.95   # arg-max agreement of the plain seeded set (near-ties at most steps); the code-path set below is held to EQUALITY
 
 
 def _crops(n, seed):
