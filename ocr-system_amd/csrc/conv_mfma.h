@@ -39,12 +39,15 @@ struct ConvParams {
     // channel-blocked tensors [n][C/16][H][W][16] (conv_ring.hip only): a 16-channel chunk of a pixel row is contiguous, every
     // chunk pass of the K loop touches its own cache lines exactly once (NHWC: 32 bytes of every 128-byte line per pass)
     int x_blk, y_blk, res_blk;
-    // multi-source input (conv_ring.hip only): the Cin input channels are the concatenation of n_src NHWC tensors of Cin / n_src
-    // channels each, source k stored at 1 / 2^xs_shift[k] of the resolution and read nearest-upsampled — DBHead's conv over the FPN
-    // concat [up8(p5), up4(p4), up2(p3), p2] without the concat ever being written.  n_src <= 1: the single tensor x.
+    // multi-source input (conv_ring.hip only): the Cin input channels are the concatenation of n_src NHWC tensors, source k
+    // contributing xs_nchunk[k] chunks of 16 channels out of pixels xs_cstride[k] elements apart (a channel slice of a wider tensor:
+    // xs[k] points at the slice's first channel), stored at 1 / 2^xs_shift[k] of the resolution and read nearest-upsampled —
+    // DBHead's conv over the FPN concat [up8(p5), up4(p4), up2(p3), p2] and the composed FPN p2 over [c2, up2(out3)] without a
+    // concat or an upsampled tensor ever being written.  n_src <= 1: the single tensor x.
     int n_src;
     const bf16_t* xs[4];
     int xs_shift[4];
+    int xs_nchunk[4], xs_cstride[4];
 };
 
 struct ConvKernelCfg {

@@ -91,12 +91,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_ring_kernel(c
         return t;
     };
 
-    // multi-source input: chunk c comes from source c / cps, stored at 1 / 2^shift of the resolution with Cin / n_src channels
-    const int nsrc = p.n_src > 1 ? p.n_src : 1, cps = nchunks / nsrc;
+    // multi-source input: source k supplies xs_nchunk[k] consecutive chunks, stored at 1 / 2^shift of the resolution, pixels xs_cstride[k] apart
+    const int nsrc = p.n_src > 1 ? p.n_src : 1;
     // (selected with constant indices: indexing the kernel argument with a run-time `src` makes hipcc copy the struct to scratch,
     // and scratch loads queue with the LDS-DMA on the vector-memory counter)
     auto src_shift = [&](int src) { return src == 0 ? p.xs_shift[0] : (src == 1 ? p.xs_shift[1] : (src == 2 ? p.xs_shift[2] : p.xs_shift[3])); };
     auto src_ptr = [&](int src) { return src == 0 ? p.xs[0] : (src == 1 ? p.xs[1] : (src == 2 ? p.xs[2] : p.xs[3])); };
+    auto src_nchunk = [&](int src) { return src == 0 ? p.xs_nchunk[0] : (src == 1 ? p.xs_nchunk[1] : (src == 2 ? p.xs_nchunk[2] : p.xs_nchunk[3])); };
+    auto src_cstride = [&](int src) { return src == 0 ? p.xs_cstride[0] : (src == 1 ? p.xs_cstride[1] : (src == 2 ? p.xs_cstride[2] : p.xs_cstride[3])); };
     // halo pieces of this thread: piece i = tid + 256 * it is slice c of halo pixel (hy, hx) — the same for every tile, so the
     // divisions are done once and kept packed, two pieces per register (left to itself hipcc hoists the unpacked (hy, hx) of all
     // ten pieces out of the tile loop, spills them, and reloads them from scratch in the middle of a chunk: a scratch load sits
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_ring_kernel(c
     // ... and their global offsets for the tile / source being requested
     int a_goff[R_AIT];
     auto describe = [&](const RingTile& t, int src) {
-        const int sh = nsrc > 1 ? src_shift(src) : 0, cin_s = nsrc > 1 ? 16 * cps : p.Cin, ws = p.W >> sh;
+        const int sh = nsrc > 1 ? src_shift(src) : 0, cin_s = nsrc > 1 ? src_cstride(src) : p.Cin, ws = p.W >> sh;
 #pragma unroll
         for (int j = 0; j < (R_AIT + 1) / 2; ++j) asm volatile("" : "+v"(a_item[j]));   // opaque: the unpacking below stays inside the tile loop
 #pragma unroll
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_ring_kernel(c
     const bf16_t* ximg;
     const bf16_t* wbase;
     auto rebase = [&](const RingTile& t, int src) {
-        if (nsrc > 1) { const int sh = src_shift(src); ximg = src_ptr(src) + (size_t)t.n_img * (p.H >> sh) * (p.W >> sh) * (16 * cps); }
+        if (nsrc > 1) { const int sh = src_shift(src); ximg = src_ptr(src) + (size_t)t.n_img * (p.H >> sh) * (p.W >> sh) * src_cstride(src); }
         else ximg = p.x + (size_t)t.n_img * p.H * p.W * p.Cin;
         wbase = p.wpk + (size_t)t.ntile * nchunks * (R_W_ITEMS * 8);
     };
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_ring_kernel(c
     RingTile nxt = cur;
     describe(cur, 0); rebase(cur, 0);
     int boff = 0;
+    int src_n = 0, src_end = nsrc > 1 ? src_nchunk(0) : 0;   // source of the chunk being requested / first chunk of the next source
     const bf16_t* xa_n = ximg;    // source of the ring slot being requested: (tile, chunk) after the one being computed
     const bf16_t* ws_n = wbase;
 #pragma unroll
@@ -400,8 +403,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_ring_kernel(c
             __syncthreads();
             RING_T(t_bar)
             if (chunk + 1 < nchunks) {
-                if (nsrc > 1 && (chunk + 1) % cps == 0) {   // the next chunk is the first of another source tensor
-                    describe(cur, (chunk + 1) / cps); rebase(cur, (chunk + 1) / cps);
+                if (nsrc > 1 && chunk + 1 == src_end) {   // the next chunk is the first of another source tensor
+                    ++src_n; src_end += src_nchunk(src_n);
+                    describe(cur, src_n); rebase(cur, src_n);
                     xa_n = ximg;
                 } else xa_n += chunk_adv;
                 ws_n += R_W_ITEMS * 8;
@@ -409,6 +413,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_ring_kernel(c
                 nxt = decode(next_lid);
                 describe(nxt, 0); rebase(nxt, 0);
                 xa_n = ximg; ws_n = wbase;
+                if (nsrc > 1) { src_n = 0; src_end = src_nchunk(0); }
             } else if (nsrc > 1) {             // no next tile: the spare request must still read valid memory -> this tile's first source again
                 describe(cur, 0); rebase(cur, 0);
                 xa_n = ximg;
@@ -454,9 +459,15 @@ bool conv_ring_supported(const ConvKernelCfg& cfg, const ConvParams& p) {
     if (p.out_mode == OUT_POOL && (p.act != ACT_RELU || p.res != nullptr)) return false;   // the pool compares bf16 bit patterns: values must be >= 0
     if (p.Cin < 32 || p.Cin % 16 != 0 || p.Cout % 64 != 0 || p.Cout * 4 > R_BIAS_BYTES || p.Ho != p.H || p.Wo != p.W) return false;
     if (p.n_src > 1) {   // chunks per source >= 2 (the peeled first chunk requests chunk 1 of the same source), whole low-resolution pixels
-        if (p.n_src > 4 || p.Cin % (16 * p.n_src) != 0 || p.Cin / (16 * p.n_src) < 2 || p.x_blk || p.out_mode != OUT_NORMAL) return false;
-        for (int k = 0; k < p.n_src; ++k)
+        if (p.n_src > 4 || p.x_blk || p.out_mode != OUT_NORMAL) return false;
+        int chunks = 0;
+        for (int k = 0; k < p.n_src; ++k) {
             if (p.xs[k] == nullptr || p.xs_shift[k] < 0 || p.xs_shift[k] > 3 || p.H % (1 << p.xs_shift[k]) != 0 || p.W % (1 << p.xs_shift[k]) != 0) return false;
+            if (p.xs_nchunk[k] < 2 || p.xs_cstride[k] < 16 * p.xs_nchunk[k] || p.xs_cstride[k] % 8 != 0) return false;
+            if ((long long)(p.H >> p.xs_shift[k]) * (p.W >> p.xs_shift[k]) * p.xs_cstride[k] >= (1ll << 31)) return false;
+            chunks += p.xs_nchunk[k];
+        }
+        if (chunks * 16 != p.Cin) return false;
     }
     if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
     if (p.res != nullptr && (p.res_shift != 0 || p.res_h != p.H || p.res_w != p.W || p.res_cstride % 4 != 0 || (long long)p.H * p.W * p.res_cstride >= (1ll << 31))) return false;

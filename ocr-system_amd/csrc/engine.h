@@ -14,8 +14,12 @@ struct Tensor4 {
     bf16_t* p = nullptr;
     int n = 0, h = 0, w = 0, c = 0;
     bool blk = false;  // channel-blocked layout [n][c/16][h][w][16] instead of NHWC (conv_mfma.h: ConvParams::x_blk)
-    // virtual concat (ConvParams::n_src): the c channels are n_src tensors of c / n_src channels, source k at 1 / 2^shift[k] resolution
+    // virtual concat (ConvParams::n_src): the c channels are n_src tensors, source k at 1 / 2^shift[k] resolution contributing xs_c[k]
+    // channels (0: c / n_src) out of pixels xs_cs[k] channels wide (0: xs_c[k])
     int n_src = 0; const bf16_t* xs[4] = {nullptr, nullptr, nullptr, nullptr}; int xs_shift[4] = {0, 0, 0, 0};
+    int xs_c[4] = {0, 0, 0, 0}, xs_cs[4] = {0, 0, 0, 0};
+    int src_c(int k) const { return xs_c[k] ? xs_c[k] : c / n_src; }
+    int src_cs(int k) const { return xs_cs[k] ? xs_cs[k] : src_c(k); }
     size_t elems() const { return (size_t)n * h * w * c; }
 };
 
@@ -34,6 +38,7 @@ struct ConvLayer {
     int launch_group = 0;     // > 0: images per launch (measured: the 256-channel 1/4-resolution layers run 7 % faster in launches of 16 pages than of 64)
     bool small_only = false;  // never switch to the 16x32-tile kernel (layers whose maps are only 4-8 rows high)
     bf16_t* fuse_w = nullptr; float fuse_b = 0.f;  // optional fused DBHead tail (see ConvParams)
+    double alg_flop_per_px = 0;   // > 0: algorithmic FLOP per output pixel of the architecture's layers this launch replaces (a composed layer executes more)
     float* bias = nullptr;  // device, n_tiles*BN
 };
 
@@ -103,6 +108,7 @@ struct lumina_ocr {
     int svtr_f16 = -1;      // storage type of the next SVTR load: -1 = what the blob's svtr.config says, 0 bf16, 1 fp16
     int conv2d_variant = 0; // lumina_ocr_conv2d: 0 = the layer's default kernel, 1 = LDS-DMA 16x32 tile, 2 = ring kernel (tests)
     int ring_orient = -1;   // its tile orientation: -1 auto, 0 / 1 forced (tests)
+    bool fpn_compose = true;  // the lateral fpn.in2 composed into fpn.p2 (the 256-channel 1/4-resolution lateral is never computed); needs fpn_multi
     bool fpn_multi = true;  // head.conv1 reads p5 / p4 / p3 / p2 at their own resolution (ring kernel): the FPN concat is never written
     bool fuse_stem = true;  // stem.conv1 + stem.conv2 in one kernel (the first 32-channel tensor stays in LDS)
     bool fuse_mb = true;    // recogniser blocks: expand + depthwise in one kernel (the expanded tensor stays in LDS)

@@ -154,6 +154,51 @@ static bool make_conv(lumina_ocr* eng, const std::map<std::string, HostBlobTenso
     return true;
 }
 
+static inline float host_bf16_to_f32(bf16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline bf16_t host_f32_to_bf16(float f) {   // round to nearest even (finite inputs)
+    uint32_t u; memcpy(&u, &f, 4);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// The lateral fpn.in2 (1x1, 64 -> 256, no bias in DBFPN) composed into the smoothing conv fpn.p2 (3x3, 256 -> 64):
+//     p2 = conv3x3(W_p2, W_in2 c2 + up2(out3)) = conv3x3(W_c, c2) + conv3x3(W_p2, up2(out3)),   W_c[co][tap][ci] = sum_m W_p2[co][tap][m] W_in2[m][ci]
+// -> layer "fpn.p2c": ONE 3x3 conv over the 320 channels [c2 (64, full resolution) | out3 (256, half resolution, read nearest-upsampled)];
+// the 256-channel 1/4-resolution lateral (1.5 GB per 16 A4 pages, written by one kernel and read back by the next) never exists.
+// W_c is formed in fp64 in m order, rounded to fp32 and then to bf16 (oracle/nets.py compose_fpn_p2 does the same, bit for bit); the
+// lateral sum is no longer rounded to bf16 on its way.  Exact with zero padding only for a lateral without bias — which is what
+// DBFPN has; a blob with a non-zero fpn.in2 bias keeps the two-kernel path.
+static int compose_fpn_p2(lumina_ocr* eng, const std::map<std::string, HostBlobTensor>& m) {
+    const HostBlobTensor *wi, *bi, *wp, *bp;
+    if (!get_wb(eng, m, "fpn.in2", &wi, &bi) || !get_wb(eng, m, "fpn.p2", &wp, &bp)) return 1;
+    const float* b_in2 = reinterpret_cast<const float*>(bi->data);
+    for (int i = 0; i < 256; ++i)
+        if (b_in2[i] != 0.f) return 0;   // (no "fpn.p2c" entry: det_forward_sub keeps in2 -> p2)
+    const bf16_t* Wi = reinterpret_cast<const bf16_t*>(wi->data);   // [256][1][1][64]
+    const bf16_t* Wp = reinterpret_cast<const bf16_t*>(wp->data);   // [64][3][3][256]
+    std::vector<bf16_t> w((size_t)64 * 9 * 320);
+    std::vector<double> win((size_t)256 * 64);
+    for (size_t i = 0; i < win.size(); ++i) win[i] = (double)host_bf16_to_f32(Wi[i]);
+    for (int co = 0; co < 64; ++co)
+        for (int t = 0; t < 9; ++t) {
+            double acc[64] = {0};
+            const bf16_t* row = Wp + ((size_t)co * 9 + t) * 256;
+            for (int mm = 0; mm < 256; ++mm) {
+                const double a = (double)host_bf16_to_f32(row[mm]);
+                for (int ci = 0; ci < 64; ++ci) acc[ci] += a * win[(size_t)mm * 64 + ci];
+            }
+            bf16_t* dst = &w[((size_t)co * 9 + t) * 320];
+            for (int ci = 0; ci < 64; ++ci) dst[ci] = host_f32_to_bf16((float)acc[ci]);
+            memcpy(dst + 64, row, 256 * sizeof(bf16_t));
+        }
+    std::map<std::string, HostBlobTensor> mm;
+    mm["fpn.p2c.w"] = HostBlobTensor{1, {64, 3, 3, 320}, reinterpret_cast<const uint8_t*>(w.data()), w.size() * sizeof(bf16_t)};
+    mm["fpn.p2c.b"] = *bp;
+    ConvLayer& L = eng->det["fpn.p2c"];
+    if (!make_conv(eng, mm, "fpn.p2c", 3, 1, 320, 64, 320, 64, ACT_NONE, &L)) return 1;
+    L.alg_flop_per_px = 2.0 * 64 * 256 + 2.0 * 9 * 256 * 64;   // the architecture's fpn.in2 + fpn.p2 (the composed conv executes 2 * 9 * 320 * 64)
+    return 0;
+}
+
 int eng_load_det(lumina_ocr* eng, const void* blob, size_t n) {
     std::map<std::string, HostBlobTensor> m;
     if (!parse_blob(eng, blob, n, &m)) return 1;
@@ -193,6 +238,7 @@ int eng_load_det(lumina_ocr* eng, const void* blob, size_t n) {
         if (!add("fpn.p" + std::to_string(l), 3, 1, 256, 64, ACT_NONE)) return 1;
     }
     if (!add("head.conv1", 3, 1, 256, 64, ACT_RELU)) return 1;
+    if (compose_fpn_p2(eng, m)) return 1;
     {
         ConvLayer& L = eng->det["head.convt2"];
         if (!make_conv(eng, m, "head.convt2", 1, 1, 64, 256, 64, 256, ACT_RELU, &L, 4)) return 1;
@@ -245,8 +291,8 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         for (int b0 = 0; b0 < x.n; b0 += L.launch_group) {
             const int nb = x.n - b0 < L.launch_group ? x.n - b0 : L.launch_group;
             Tensor4 xs = x, ys = *y, rs;
-            xs.n = nb; xs.p = x.p + (size_t)b0 * x.h * x.w * (x.n_src > 1 ? x.c / x.n_src : x.c);
-            for (int k = 0; k < x.n_src; ++k) xs.xs[k] = x.xs[k] + (size_t)b0 * (x.h >> x.xs_shift[k]) * (x.w >> x.xs_shift[k]) * (x.c / x.n_src);
+            xs.n = nb; xs.p = x.p + (size_t)b0 * x.h * x.w * (x.n_src > 1 ? x.src_cs(x.n_src - 1) : x.c);   // (multi-source: p is the last source)
+            for (int k = 0; k < x.n_src; ++k) xs.xs[k] = x.xs[k] + (size_t)b0 * (x.h >> x.xs_shift[k]) * (x.w >> x.xs_shift[k]) * x.src_cs(k);
             ys.n = nb; ys.p = y->p + (size_t)b0 * ystride;
             if (res) { rs = *res; rs.n = nb; rs.p = res->p + (size_t)b0 * res->h * res->w * res->c; }
             if (eng_run_conv(eng, one, xs, &ys, res ? &rs : nullptr, res_shift, out_mode, up_shift, y_cstride, y_coff, flat, st, gate)) return 1;
@@ -279,7 +325,10 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     p.res_shift = res_shift;
     p.x_blk = x.blk; p.y_blk = y->blk; p.res_blk = res ? res->blk : 0;
     p.n_src = x.n_src;
-    for (int k = 0; k < 4; ++k) { p.xs[k] = x.xs[k]; p.xs_shift[k] = x.xs_shift[k]; }
+    for (int k = 0; k < 4; ++k) {
+        p.xs[k] = x.xs[k]; p.xs_shift[k] = x.xs_shift[k];
+        p.xs_nchunk[k] = k < x.n_src ? x.src_c(k) / 16 : 0; p.xs_cstride[k] = k < x.n_src ? x.src_cs(k) : 0;
+    }
     p.res_cstride = res ? res->c : 0;
     p.y_cstride = y_cstride ? y_cstride : y->c;
     p.y_coff = y_coff;
@@ -292,7 +341,7 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     }
     if (out_mode == OUT_POOL && (L.wpk_big == nullptr || L.cfg_big.nw != 6)) return locr_fail(eng, "fused max pool needs the LDS-DMA conv kernel", L.name.c_str());
     // 16x32 tiles (less LDS and L2 traffic per MFMA) once they still give >= 2 workgroups per CU on all 256 CUs twice over
-    const bool use_big = out_mode == OUT_POOL || conv_takes_big(eng, L, p.N, p.Ho, p.Wo, flat);
+    const bool use_big = out_mode == OUT_POOL || p.n_src > 1 || conv_takes_big(eng, L, p.N, p.Ho, p.Wo, flat);   // (a multi-source input is the ring kernel's)
     if (L.force_big && eng->conv2d_variant == 2 && !conv_ring_supported(L.cfg_big, p)) return locr_fail(eng, "conv2d_variant 2: the ring kernel does not take this layer", L.name.c_str());
     ConvKernelCfg cfg = L.cfg;
     if (use_big) { cfg = L.cfg_big; p.wpk = L.wpk_big; }
@@ -307,10 +356,10 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         HIPCHK(hipEventRecord(e1, st));
         eng->conv_events.push_back({e0, e1});
         const double px = flat ? (double)p.pix_limit : (double)p.N * p.Ho * p.Wo;
-        eng->conv_flops.push_back(2.0 * px * L.ks * L.ks * L.cin * L.cout);
+        eng->conv_flops.push_back(L.alg_flop_per_px > 0 ? px * L.alg_flop_per_px : 2.0 * px * L.ks * L.ks * L.cin * L.cout);
         // algorithmic HBM bytes: input once + output once (+ residual) + weights once
         double in_elems = (double)x.elems();
-        if (x.n_src > 1) { in_elems = 0; for (int k = 0; k < x.n_src; ++k) in_elems += (double)x.n * (x.h >> x.xs_shift[k]) * (x.w >> x.xs_shift[k]) * (x.c / x.n_src); }
+        if (x.n_src > 1) { in_elems = 0; for (int k = 0; k < x.n_src; ++k) in_elems += (double)x.n * (x.h >> x.xs_shift[k]) * (x.w >> x.xs_shift[k]) * x.src_c(k); }
         eng->conv_bytes.push_back(2.0 * (in_elems + px * (out_mode == OUT_CONVT && p.fuse_w ? 4.0 : (double)L.cout) * (out_mode == OUT_UPSAMPLE ? (double)(1 << (2 * up_shift)) : (out_mode == OUT_POOL ? 0.25 : 1.0)) + (res ? px * (double)L.cout / (double)(1 << (2 * res_shift)) : 0.0) + (double)L.ks * L.ks * L.cin * L.cout));
         eng->conv_names.push_back(L.name);
         std::string kname = use_pw ? (L.cin == 64 ? "conv_pw_kernel<64>" : "conv_pw_kernel<128>") : conv_kernel_name(cfg);
@@ -411,6 +460,22 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
         if (t.p) r.p = t.p + (size_t)b0 * t.h * t.w * t.c;
         return r;
     };
+    // fpn.p2.  Default: ONE conv over [c2 | up2(out3)] with the lateral fpn.in2 composed into its weights (compose_fpn_p2; ring kernel,
+    // multi-source input, whatever the page size: the arithmetic definition must not depend on which kernel a geometry selects) —
+    // the 256-channel 1/4-resolution lateral is never computed.  Otherwise (option fpn_compose = 0, ring kernel off, a lateral with
+    // a bias): in2 -> lateral tensor -> p2.
+    const bool compose = eng->fpn_compose && eng->conv_ring && D.count("fpn.p2c") != 0;
+    auto run_p2 = [&](const Tensor4& c2, const Tensor4& o3, Tensor4* lateral, Tensor4* dst, int y_cstride, int y_coff) -> int {
+        if (compose) {
+            Tensor4 in = c2;
+            in.c = 320; in.n_src = 2;
+            in.xs[0] = c2.p; in.xs[1] = o3.p; in.p = o3.p;
+            in.xs_shift[0] = 0; in.xs_shift[1] = 1; in.xs_c[0] = 64; in.xs_c[1] = 256;
+            return eng_run_conv(eng, D["fpn.p2c"], in, dst, nullptr, 0, OUT_NORMAL, 0, y_cstride, y_coff, false, st);
+        }
+        RUN(eng_run_conv(eng, D["fpn.in2"], c2, lateral, &o3, 1, OUT_NORMAL, 0, 0, 0, false, st));
+        return eng_run_conv(eng, D["fpn.p2"], *lateral, dst, nullptr, 0, OUT_NORMAL, 0, y_cstride, y_coff, false, st);
+    };
     auto head_tail = [&](const Tensor4& h1, bf16_t* prob_g, int nb) -> int {
         Tensor4 pm; pm.p = dry ? nullptr : prob_g; pm.n = nb; pm.h = Hp; pm.w = Wp; pm.c = 1;
         if (eng->fuse_head && eng->keep_taps != 1)   // DBHead tail in one launch: the 64-channel 1/2-resolution tensor never exists
@@ -429,13 +494,15 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
         // 64 A4 pages in one forward: p2 3.68 -> 3.47 ms, head.conv1 3.32 -> 3.12 ms), and the 256-channel lateral only ever exists for
         // one group.  Launch order only: results are per page.
         const int G = (eng->keep_taps == 0 && eng->tail_group > 0 && B > eng->tail_group) ? eng->tail_group : B;
-        Tensor4 out2 = ws_tensor(eng, G, feats[0].h, feats[0].w, 256), p2 = ws_tensor(eng, G, feats[0].h, feats[0].w, 64);
+        Tensor4 out2{};
+        if (!compose) out2 = ws_tensor(eng, G, feats[0].h, feats[0].w, 256);
+        Tensor4 p2 = ws_tensor(eng, G, feats[0].h, feats[0].w, 64);
         Tensor4 h1 = ws_tensor(eng, G, Hp / 4, Wp / 4, 64);
         for (int g0 = 0; g0 < B; g0 += G) {
             const int nb = B - g0 < G ? B - g0 : G;
             Tensor4 o2 = slice(out2, 0, nb), p2g = slice(p2, 0, nb), h1g = slice(h1, 0, nb), o3 = slice(out3, g0, nb);
-            RUN(eng_run_conv(eng, D["fpn.in2"], slice(feats[0], g0, nb), &o2, &o3, 1, OUT_NORMAL, 0, 0, 0, false, st));
-            RUN(eng_run_conv(eng, D["fpn.p2"], o2, &p2g, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "fpn.p2", p2g);
+            RUN(run_p2(slice(feats[0], g0, nb), o3, &o2, &p2g, 0, 0));
+            tap(eng, "fpn.p2", p2g);
             Tensor4 cat = p2g;
             cat.c = 256; cat.n_src = 4;
             cat.xs[0] = slice(p5, g0, nb).p; cat.xs[1] = slice(p4, g0, nb).p; cat.xs[2] = slice(p3, g0, nb).p; cat.xs[3] = p2g.p;
@@ -445,14 +512,14 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
         }
         return 0;
     }
-    Tensor4 out2 = ws_tensor(eng, B, feats[0].h, feats[0].w, 256);
-    RUN(eng_run_conv(eng, D["fpn.in2"], feats[0], &out2, &out3, 1, OUT_NORMAL, 0, 0, 0, false, st));
+    Tensor4 out2{};
+    if (!compose) out2 = ws_tensor(eng, B, feats[0].h, feats[0].w, 256);
     // smooth convs write straight into the channel slices of the 1/4-resolution concat (replicated)
     Tensor4 fuse = ws_tensor(eng, B, Hp / 4, Wp / 4, 256);
     RUN(eng_run_conv(eng, D["fpn.p5"], in5, &fuse, nullptr, 0, OUT_UPSAMPLE, 3, 256, 0, false, st));
     RUN(eng_run_conv(eng, D["fpn.p4"], out4, &fuse, nullptr, 0, OUT_UPSAMPLE, 2, 256, 64, false, st));
     RUN(eng_run_conv(eng, D["fpn.p3"], out3, &fuse, nullptr, 0, OUT_UPSAMPLE, 1, 256, 128, false, st));
-    RUN(eng_run_conv(eng, D["fpn.p2"], out2, &fuse, nullptr, 0, OUT_NORMAL, 0, 256, 192, false, st));
+    RUN(run_p2(feats[0], out3, &out2, &fuse, 256, 192));
     tap(eng, "fpn.fuse", fuse);
     Tensor4 h1 = ws_tensor(eng, B, Hp / 4, Wp / 4, 64);
     RUN(eng_run_conv(eng, hc1, fuse, &h1, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st)); tap(eng, "head.conv1", h1);

@@ -95,9 +95,29 @@ def det_normalize(pages_u8: np.ndarray, hp: int, wp: int, mode="bf16") -> torch.
     return _rb(t, mode)
 
 
+def compose_fpn_p2(wd: Dict[str, np.ndarray]):
+    """The lateral fpn.in2 (1x1, no bias in DBFPN) composed into the smoothing conv fpn.p2:
+        p2 = conv3x3(W_p2, W_in2 c2 + up2(out3)) = conv3x3(W_c, c2) + conv3x3(W_p2, up2(out3)),  W_c[co,tap,ci] = sum_m W_p2[co,tap,m] W_in2[m,ci]
+    -> OHWI weights [64,3,3,320] over the channels [c2 | up2(out3)], or None when fpn.in2 carries a bias (zero padding would then make
+    the composition inexact at the border: the engine keeps the two-kernel path, csrc/engine.hip compose_fpn_p2).
+    W_c is summed in fp64 in m order (products of bf16 values are exact in fp64), rounded to fp32, then to bf16 — the engine's loader
+    does the same operations in the same order."""
+    if np.any(wd["fpn.in2.b"] != 0):
+        return None
+    w_in2 = wd["fpn.in2.w"].reshape(256, 64).astype(np.float64)
+    w_p2 = wd["fpn.p2.w"].astype(np.float64)                       # [64,3,3,256]
+    acc = np.zeros((64, 3, 3, 64), np.float64)
+    for m in range(256):
+        acc += w_p2[:, :, :, m, None] * w_in2[m][None, None, None, :]
+    wc = arch.bf16_round(acc.astype(np.float32))
+    return np.concatenate([wc, wd["fpn.p2.w"].astype(np.float32)], axis=3)
+
+
 def det_forward(wd: Dict[str, np.ndarray], pages_u8: np.ndarray, hp: Optional[int] = None,
-                wp: Optional[int] = None, mode: str = "bf16", taps: Optional[dict] = None) -> np.ndarray:
-    """pages [B,H,W,3] u8 -> probability map [B,hp,wp] float32 (bf16-exact in mode bf16)."""
+                wp: Optional[int] = None, mode: str = "bf16", taps: Optional[dict] = None, compose: bool = True) -> np.ndarray:
+    """pages [B,H,W,3] u8 -> probability map [B,hp,wp] float32 (bf16-exact in mode bf16).
+    compose: fpn.p2 through the composed weights (compose_fpn_p2; the engine's default) — the lateral sum out2 is then never
+    rounded to bf16; False: the two-step definition (engine option fpn_compose = 0)."""
     b, h, w, _ = pages_u8.shape
     hp = hp or (h + 31) // 32 * 32
     wp = wp or (w + 31) // 32 * 32
@@ -132,11 +152,17 @@ def det_forward(wd: Dict[str, np.ndarray], pages_u8: np.ndarray, hp: Optional[in
         in5 = conv_bn_act(c5, wd, "fpn.in5", 1, "none", mode=mode)
         out4 = conv_bn_act(c4, wd, "fpn.in4", 1, "none", residual=F.interpolate(in5, scale_factor=2, mode="nearest"), mode=mode)
         out3 = conv_bn_act(c3, wd, "fpn.in3", 1, "none", residual=F.interpolate(out4, scale_factor=2, mode="nearest"), mode=mode)
-        out2 = conv_bn_act(c2, wd, "fpn.in2", 1, "none", residual=F.interpolate(out3, scale_factor=2, mode="nearest"), mode=mode)
         p5 = conv_bn_act(in5, wd, "fpn.p5", 1, "none", mode=mode); tap("fpn.p5", p5)
         p4 = conv_bn_act(out4, wd, "fpn.p4", 1, "none", mode=mode); tap("fpn.p4", p4)
         p3 = conv_bn_act(out3, wd, "fpn.p3", 1, "none", mode=mode); tap("fpn.p3", p3)
-        p2 = conv_bn_act(out2, wd, "fpn.p2", 1, "none", mode=mode); tap("fpn.p2", p2)
+        wc = compose_fpn_p2(wd) if compose else None
+        if wc is not None:     # ONE 3x3 conv over [c2 | up2(out3)] (320 channels), fp32 accumulate, one rounding
+            cat = torch.cat([c2, F.interpolate(out3, scale_factor=2, mode="nearest")], dim=1)
+            p2 = conv_bn_act(cat, {"fpn.p2c.w": wc, "fpn.p2c.b": wd["fpn.p2.b"]}, "fpn.p2c", 1, "none", mode=mode)
+        else:
+            out2 = conv_bn_act(c2, wd, "fpn.in2", 1, "none", residual=F.interpolate(out3, scale_factor=2, mode="nearest"), mode=mode)
+            p2 = conv_bn_act(out2, wd, "fpn.p2", 1, "none", mode=mode)
+        tap("fpn.p2", p2)
         fuse = torch.cat([F.interpolate(p5, scale_factor=8, mode="nearest"),
                           F.interpolate(p4, scale_factor=4, mode="nearest"),
                           F.interpolate(p3, scale_factor=2, mode="nearest"), p2], dim=1)

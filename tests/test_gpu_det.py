@@ -128,7 +128,7 @@ def test_det_taps_vs_oracle_with_the_production_kernels(engine, any_det_weights,
     assert sum(k.startswith(want) for k in names) >= 10, names
     assert any(k.startswith("conv_ring_kernel<0,false,true") or k.endswith(",4,4>") for k in names), names   # pooled stem.conv3
     taps = {}
-    ref = nets.det_forward(any_det_weights, pages, mode="bf16", taps=taps)
+    ref = nets.det_forward(any_det_weights, pages, mode="bf16", taps=taps, compose=bool(ring))   # (fpn.p2 is composed with fpn.in2 on the ring kernel only)
     stats = {name: close_stats(got[name], taps[name]) for name in got if name != "prob"}
     assert "fpn.fuse" in stats or "fpn.p2" in stats
     p = arch.bf16_bits_to_f32(got["prob"].view(np.uint16))
@@ -168,6 +168,61 @@ def test_head_reads_fpn_maps_at_their_own_resolution_bit_identically(engine, any
     # the four maps are the channel slices of the concat, sub-sampled
     for k, (name, s_) in enumerate((("fpn.p5", 8), ("fpn.p4", 4), ("fpn.p3", 2), ("fpn.p2", 1))):
         assert np.array_equal(a[name], ref["fpn.fuse"][:, ::s_, ::s_, 64 * k:64 * k + 64]), name
+
+
+@pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901)], ids=lambda s: "b%d_%dx%d" % s)
+def test_fpn_p2_composed_with_its_lateral(engine, det_weights, dense_det_weights, shape):
+    """Default: fpn.p2 is ONE conv over [c2 | up2(out3)] with the lateral fpn.in2 composed into its weights (engine.hip
+    compose_fpn_p2 / oracle nets.compose_fpn_p2); option fpn_compose = 0: in2 -> 256-channel lateral -> p2.  Each against its own
+    oracle definition; the composed weights themselves bit for bit (the tap of a one-hot input would need a test hook: instead the
+    p2 tap of the composed path must be CLOSER to the composed oracle than to the two-step one); on the hand-set text path (exact
+    arithmetic) the two definitions give the identical probability map; a lateral with a bias falls back to two kernels."""
+    from oracle import nets
+    b, h, w = shape
+    pages = _pages(b, h, w, 77)
+    pd = torch.from_numpy(pages).cuda()
+    engine.set_option("conv_big_min", 1)
+    try:
+        engine.load_det(dense_det_weights)
+        got = {}
+        for comp in (1, 0):
+            engine.set_option("fpn_compose", comp)
+            got[comp] = _forward_all(engine, pd)
+        ref = {}
+        for comp in (1, 0):
+            t = {}
+            nets.det_forward(dense_det_weights, pages, taps=t, compose=bool(comp))
+            ref[comp] = t
+        for comp in (1, 0):
+            st = close_stats(got[comp]["fpn.p2"], ref[comp]["fpn.p2"])
+            assert st["within4"] > 0.85 and st["mean_abs"] < 0.01 * st["ref_mean_abs"], (comp, st)
+        assert not np.array_equal(got[1]["fpn.p2"], got[0]["fpn.p2"])
+        own = np.abs(got[1]["fpn.p2"].astype(np.float64) - ref[1]["fpn.p2"]).mean()
+        other = np.abs(got[1]["fpn.p2"].astype(np.float64) - ref[0]["fpn.p2"]).mean()
+        assert own < other, (own, other)
+        for name in ("s0.b1", "s1.b1"):                                    # everything upstream of p2 is untouched
+            assert np.array_equal(got[1][name], got[0][name])
+        # text path: exact arithmetic on channel 0 -> the same probability bits either way
+        engine.load_det(det_weights)
+        engine.set_option("fpn_compose", 1)
+        a = engine.det_forward(pd).clone()
+        engine.set_option("fpn_compose", 0)
+        bb = engine.det_forward(pd).clone()
+        assert torch.equal(a.view(torch.int16), bb.view(torch.int16))
+        # a lateral WITH a bias cannot be composed exactly under zero padding: the loader keeps the two-kernel path
+        wb = {k: v.copy() for k, v in dense_det_weights.items()}
+        wb["fpn.in2.b"][:] = 0.25
+        engine.load_det(wb)
+        engine.set_option("fpn_compose", 1)
+        g = _forward_all(engine, pd)
+        t = {}
+        nets.det_forward(wb, pages, taps=t)
+        assert nets.compose_fpn_p2(wb) is None
+        st = close_stats(g["fpn.p2"], t["fpn.p2"])
+        assert st["within4"] > 0.85, st
+    finally:
+        engine.set_option("fpn_compose", 1)
+        engine.set_option("conv_big_min", 1024)
 
 
 def test_grouped_quarter_resolution_tail_is_invisible(engine, any_det_weights):
@@ -391,6 +446,7 @@ def test_ring_conv_kernel_is_bit_identical(engine, any_det_weights, shape, orien
     pages = torch.from_numpy(_pages(b, h, w, 41)).cuda()
     engine.load_det(any_det_weights)
     engine.set_option("conv_big_min", 1)      # the 16x32-tile kernels on every layer that has them, however small the page
+    engine.set_option("fpn_compose", 0)       # (kernels are compared here, not definitions: fpn.p2 in its two-step form on both sides)
     try:
         engine.set_option("conv_ring", 0)
         ref = _forward_all(engine, pages)
@@ -404,6 +460,7 @@ def test_ring_conv_kernel_is_bit_identical(engine, any_det_weights, shape, orien
         engine.set_option("ring_orient", -1)
         engine.set_option("conv_big_min", 1024)
         engine.set_option("time_convs", 0)
+        engine.set_option("fpn_compose", 1)
     assert sum(k.startswith("conv_ring_kernel") for k in names) >= 10, names
     _assert_same(a, ref, "ring vs one-tile")
 
@@ -415,6 +472,7 @@ def test_ring_conv_kernel_on_random_page_shapes(engine, any_det_weights):
     rng = np.random.default_rng(2025)
     engine.load_det(any_det_weights)
     engine.set_option("conv_big_min", 1)
+    engine.set_option("fpn_compose", 0)       # (two-step fpn.p2 on both sides, as above)
     try:
         for _ in range(10):
             b, h, w = int(rng.integers(1, 4)), int(rng.integers(64, 700)), int(rng.integers(64, 700))
@@ -427,6 +485,7 @@ def test_ring_conv_kernel_on_random_page_shapes(engine, any_det_weights):
     finally:
         engine.set_option("conv_ring", 1)
         engine.set_option("conv_big_min", 1024)
+        engine.set_option("fpn_compose", 1)
 
 
 @pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901)], ids=lambda s: "b%d_%dx%d" % s)
