@@ -89,6 +89,7 @@ int lumina_ocr_set_option(lumina_ocr_t* h, const char* key, int value) {
     else if (!strcmp(key, "fuse_stem")) h->fuse_stem = value != 0;
     else if (!strcmp(key, "fpn_multi")) h->fpn_multi = value != 0;
     else if (!strcmp(key, "fpn_compose")) h->fpn_compose = value != 0;
+    else if (!strcmp(key, "fuse_short")) h->fuse_short = value != 0;
     else if (!strcmp(key, "conv_ring")) h->conv_ring = value != 0;
     else if (!strcmp(key, "blocked_layout")) h->blocked_layout = value != 0;
     else if (!strcmp(key, "conv_big_min")) h->conv_big_min = value >= 0 ? value : 1024;

@@ -48,6 +48,14 @@ struct ConvParams {
     const bf16_t* xs[4];
     int xs_shift[4];
     int xs_nchunk[4], xs_cstride[4];
+    // fused vd shortcut (3x3 / stride-2 block-entry kernel only): the block's 2x2 / stride-2 shortcut conv reads pixels (2oy, 2ox) ..
+    // (2oy+1, 2ox+1) — taps (1,1), (1,2), (2,1), (2,2) of the 3x3 window whose halo is already in LDS.  wpk2 = that layer's packed
+    // weights (ks 2, same bn / ck), bias2 its bias; its output (no activation) goes to y2 [N, Ho, Wo, y2_cstride].  Same products in
+    // the same (chunk, tap) order as the separate kernel: bit-identical, and the input is read once instead of twice.
+    const bf16_t* wpk2;
+    const float* bias2;
+    bf16_t* y2;
+    int y2_cstride;
 };
 
 struct ConvKernelCfg {

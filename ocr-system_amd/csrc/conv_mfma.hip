@@ -37,6 +37,8 @@ struct Cfg {
     static constexpr int NTHR = NW * 64;
     static constexpr bool DMA = (DB == 3 || DB == 4);  // operands arrive by LDS-DMA (global_load_lds) into a 2-deep LDS ring
     static constexpr bool POOL = (DB == 4);            // ... and the epilogue is the fused 3x3/s2 max pool (its own instantiation)
+    static constexpr bool SC = (DB == 5);              // 3x3 / stride 2 with the block's 2x2 / stride-2 shortcut conv computed from the same halo (ConvParams::wpk2)
+    static_assert(!SC || (KS == 3 && S == 2 && CK == 16), "fused shortcut: the 3x3 / stride-2 block-entry kernel");
     static constexpr int TH = NW * MT;              // TW == 32: every wave owns MT pixel rows (MT 32-pixel MFMA column tiles)
     static constexpr int PAD = (KS == 3) ? 1 : 0;
     static constexpr int HH = (TH - 1) * S + KS;
@@ -52,6 +54,7 @@ struct Cfg {
     static constexpr int NT = BN / 32;
     static constexpr int A_BYTES = DMA ? HPX * NPL * 16 : PLANE_A * NPL * 16;
     static constexpr int W_BYTES = PLANE_W * NPL * 16;
+    static constexpr int W2_ROWS = SC ? 4 * BN : 0, W2_ITEMS = W2_ROWS * NPL, W2IT = (W2_ITEMS + NTHR - 1) / NTHR, W2_BYTES = W2_ITEMS * 16;
     // LDS addressing of one 16-byte entry (pixel or weight row, 8-channel slice): the plane layout keeps a slice's entries
     // together (register staging scatters into it); the DMA layout is the lane-linear image a wave's global_load_lds writes,
     // [pixel][slice] — with CK == 16 (two slices) a fragment read is still one contiguous, conflict-free 1 KB
@@ -59,7 +62,7 @@ struct Cfg {
     static constexpr int W_ROW = DMA ? NPL * 16 : 16, W_SL = DMA ? 16 : PLANE_W * 16;
     static constexpr int STAGE_PITCH = BN * 2 + 16;
     static constexpr int STAGE_BYTES = TH * TW * STAGE_PITCH;
-    static constexpr int BUF_BYTES = A_BYTES + W_BYTES;
+    static constexpr int BUF_BYTES = A_BYTES + W_BYTES + W2_BYTES;
     static constexpr int LDS_BYTES = (BUF_BYTES * (DMA ? 2 : 1)) > STAGE_BYTES ? (BUF_BYTES * (DMA ? 2 : 1)) : STAGE_BYTES;
     static_assert(!DMA || (CK == 16 && KS == 3 && S == 1), "DMA variant: 3x3 / stride 1 / 16-channel chunks");
     static constexpr int A_ITEMS = HH * HW * NPL;
@@ -133,6 +136,9 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
 
     uint4 a_reg[C::AIT], w_reg[C::WIT];
     uint4 g_reg[KS == 1 ? C::AIT : 1];
+    uint4 w2_reg[C::SC ? C::W2IT : 1];
+    unsigned char* sW2 = sW + C::W_BYTES;
+    const bf16_t* wbase2 = C::SC ? p.wpk2 + (size_t)ntile * nchunks * C::W2_ITEMS * 8 : nullptr;
 #define ISSUE_LOADS(chunk_)                                                                          \
     {                                                                                                \
         const bf16_t* xa = ximg + (chunk_) * cadv;                                                   \
@@ -154,6 +160,15 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
             if ((C::W_ITEMS % NTHR == 0 || i < C::W_ITEMS) && !skipw_) t_ = wsrc[i];                 \
             w_reg[it] = t_;                                                                          \
         }                                                                                            \
+        if constexpr (C::SC) {                                                                       \
+            const uint4* w2src = reinterpret_cast<const uint4*>(wbase2 + (size_t)(chunk_) * C::W2_ITEMS * 8); \
+            _Pragma("unroll") for (int it = 0; it < C::W2IT; ++it) {                                 \
+                const int i = tid + NTHR * it;                                                      \
+                uint4 t_ = make_uint4(0, 0, 0, 0);                                                   \
+                if (C::W2_ITEMS % NTHR == 0 || i < C::W2_ITEMS) t_ = w2src[i];                       \
+                w2_reg[it] = t_;                                                                     \
+            }                                                                                        \
+        }                                                                                            \
     }
 #define WRITE_LDS(boff_)                                                                             \
     {                                                                                                \
@@ -164,6 +179,12 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
         _Pragma("unroll") for (int it = 0; it < C::WIT; ++it) {                                      \
             const int i = tid + NTHR * it;                                                          \
             if (C::W_ITEMS % NTHR == 0 || i < C::W_ITEMS) *reinterpret_cast<uint4*>(sW + (boff_) + i * 16) = w_reg[it]; \
+        }                                                                                            \
+        if constexpr (C::SC) {                                                                       \
+            _Pragma("unroll") for (int it = 0; it < C::W2IT; ++it) {                                 \
+                const int i = tid + NTHR * it;                                                      \
+                if (C::W2_ITEMS % NTHR == 0 || i < C::W2_ITEMS) *reinterpret_cast<uint4*>(sW2 + (boff_) + i * 16) = w2_reg[it]; \
+            }                                                                                        \
         }                                                                                            \
     }
 
@@ -197,6 +218,15 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
         for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+    f32x16_t acc2[C::SC ? MT : 1][C::SC ? C::NT : 1];   // fused shortcut: its own accumulators
+    if constexpr (C::SC) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc2[mt][nt][j] = 0.f;
+    }
 
     // fragment read bases (bytes)
     int aoff[MT];
@@ -206,6 +236,7 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
         aoff[mt] = h * C::A_SL + ((ty * S) * C::HWP + tx * S) * C::A_PIX;
     }
     const int woff = h * C::W_SL + r * C::W_ROW;
+    const int woff2 = h * (C::W2_ROWS * 16) + r * 16;   // the shortcut's slab: plane layout, plane stride = its own row count
 
     // Fragment reads are software-pipelined one (tap, k-step) ahead of the MFMAs that consume them: the reads of step s+1 are
     // in flight while the 2*NT MFMAs of step s issue (hipcc otherwise places every ds_read right in front of its MFMA and the
@@ -227,6 +258,16 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
             _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                                                   \
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st & 1][nt], bfr[st & 1][mt], acc[mt][nt], 0, 0, 0); \
+        if constexpr (C::SC) {   /* taps (1,1) (1,2) (2,1) (2,2) of the 3x3 window are the shortcut's taps 0..3: same pixel fragments */ \
+            if (st == 4 || st == 5 || st == 7 || st == 8) {                                                        \
+                const int t2_ = (st == 4) ? 0 : (st == 5) ? 1 : (st == 7) ? 2 : 3;                                 \
+                bf16x8_t a2_[C::NT];                                                                               \
+                _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt) a2_[nt] = lds_frag(sW2 + (boff_) + woff2 + (t2_ * BN + nt * 32) * 16); \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                   \
+                    _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt)                                           \
+                        acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_[nt], bfr[st & 1][mt], acc2[mt][nt], 0, 0, 0); \
+            }                                                                                                      \
+        }                                                                                                          \
         if (st + 1 < NSTEPS) LOAD_FRAGS(boff_, st + 1, (st + 1) & 1)                                               \
         _Pragma("unroll") for (int q_ = 0; q_ < MT * C::NT; ++q_) {                                                \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA of this step ... */                     \
@@ -344,6 +385,29 @@ __global__ __launch_bounds__(NW * 64, (BN <= 64 ? 2 : 1)) void conv_mfma_kernel(
                         if (!pvalid || co >= cout_r8) continue;
                         *reinterpret_cast<uint4*>(p.y + (((size_t)n_img * p.Ho + oy) * p.Wo + ox) * p.y_cstride + p.y_coff + co) = v;
                     }
+            }
+            if constexpr (C::SC) {   // the shortcut's tile: + its bias, no activation, same store pattern into y2
+                const float* b2 = p.bias2 + ntile * BN;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int oy = oyb + wave * MT + mt, ox = oxb + r;
+                    const bool pvalid = oy < p.Ho && ox < p.Wo;
+#pragma unroll
+                    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            const int g0 = 2 * gp, g1 = 2 * gp + 1;
+                            const float4 ba = *reinterpret_cast<const float4*>(b2 + nt * 32 + 8 * g0 + 4 * h), bb = *reinterpret_cast<const float4*>(b2 + nt * 32 + 8 * g1 + 4 * h);
+                            const uint32_t q0x = pack_bf16x2(acc2[mt][nt][4 * g0 + 0] + ba.x, acc2[mt][nt][4 * g0 + 1] + ba.y), q0y = pack_bf16x2(acc2[mt][nt][4 * g0 + 2] + ba.z, acc2[mt][nt][4 * g0 + 3] + ba.w);
+                            const uint32_t q1x = pack_bf16x2(acc2[mt][nt][4 * g1 + 0] + bb.x, acc2[mt][nt][4 * g1 + 1] + bb.y), q1y = pack_bf16x2(acc2[mt][nt][4 * g1 + 2] + bb.z, acc2[mt][nt][4 * g1 + 3] + bb.w);
+                            const auto sx = __builtin_amdgcn_permlane32_swap(q0x, q1x, false, false);
+                            const auto sy = __builtin_amdgcn_permlane32_swap(q0y, q1y, false, false);
+                            const uint4 v = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                            const int co = ntile * BN + nt * 32 + 16 * gp + 8 * h;
+                            if (!pvalid || co >= cout_r8) continue;
+                            *reinterpret_cast<uint4*>(p.y2 + (((size_t)n_img * p.Ho + oy) * p.Wo + ox) * p.y2_cstride + co) = v;
+                        }
+                }
             }
             return;
         }
@@ -551,6 +615,11 @@ hipError_t conv_launch(const ConvKernelCfg& cfg, ConvParams p, hipStream_t strea
         p.tiles_y = ceil_div(p.Ho, 16);
         if (cfg.ks == 3 && cfg.stride == 1 && cfg.bn == 64 && cfg.ck == 16) return launch_t<3, 1, 64, 16, 32, 4, 0, 4>(p, stream);
         return hipErrorInvalidValue;
+    }
+    if (p.wpk2 != nullptr) {   // 3x3 / stride 2 + the block's 2x2 / stride-2 shortcut from the same halo
+        if (!(cfg.ks == 3 && cfg.stride == 2 && cfg.bn == 64 && cfg.ck == 16 && cfg.nw == 4) || p.out_mode != OUT_NORMAL || (dbg & 32) || p.bias2 == nullptr ||
+            p.y2 == nullptr || p.H % 2 != 0 || p.W % 2 != 0 || p.res != nullptr || p.y2_cstride % 8 != 0) return hipErrorInvalidValue;
+        return launch_t<3, 2, 64, 16, 32, 4, 5, 2>(p, stream);
     }
     if (p.out_mode == OUT_POOL && cfg.nw != 6) return hipErrorInvalidValue;
     if (cfg.nw == 6) {  // same tile as nw == 5, operands by LDS-DMA into a 2-deep ring (row-major weight packing)

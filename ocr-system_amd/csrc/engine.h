@@ -108,6 +108,7 @@ struct lumina_ocr {
     int svtr_f16 = -1;      // storage type of the next SVTR load: -1 = what the blob's svtr.config says, 0 bf16, 1 fp16
     int conv2d_variant = 0; // lumina_ocr_conv2d: 0 = the layer's default kernel, 1 = LDS-DMA 16x32 tile, 2 = ring kernel (tests)
     int ring_orient = -1;   // its tile orientation: -1 auto, 0 / 1 forced (tests)
+    bool fuse_short = true;   // stages 1-3: the block entry's 2x2 / stride-2 shortcut conv computed by its 3x3 / stride-2 conv0 kernel (one read of the input)
     bool fpn_compose = true;  // the lateral fpn.in2 composed into fpn.p2 (the 256-channel 1/4-resolution lateral is never computed); needs fpn_multi
     bool fpn_multi = true;  // head.conv1 reads p5 / p4 / p3 / p2 at their own resolution (ring kernel): the FPN concat is never written
     bool fuse_stem = true;  // stem.conv1 + stem.conv2 in one kernel (the first 32-channel tensor stays in LDS)
@@ -136,5 +137,7 @@ int eng_load_svtr(lumina_ocr* eng, const void* blob, size_t n);
 int eng_svtr_forward(lumina_ocr* eng, const uint8_t* crops, const int* widths, int N, int* idx, float* prob, hipStream_t st);
 int eng_ws_reserve(lumina_ocr* eng, size_t bytes);
 void* eng_ws_alloc(lumina_ocr* eng, size_t bytes);
+// short_l / short_y: the block's shortcut layer and its output, computed by the same launch (ConvParams::wpk2)
 int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4* y, const Tensor4* res, int res_shift, int out_mode,
-                 int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st, const bf16_t* gate = nullptr);
+                 int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st, const bf16_t* gate = nullptr,
+                 const ConvLayer* short_l = nullptr, Tensor4* short_y = nullptr);

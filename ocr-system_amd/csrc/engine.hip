@@ -281,7 +281,8 @@ static bool conv_takes_big(const lumina_ocr* eng, const ConvLayer& L, int n, int
 }
 
 int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4* y, const Tensor4* res, int res_shift, int out_mode,
-                 int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st, const bf16_t* gate) {
+                 int up_shift, int y_cstride, int y_coff, bool flat, hipStream_t st, const bf16_t* gate, const ConvLayer* short_l, Tensor4* short_y) {
+    if (short_l != nullptr && L.launch_group > 0) return locr_fail(eng, "fused shortcut", "not available with launch groups");
     if (L.launch_group > 0 && x.n > L.launch_group && !flat && gate == nullptr && x.p != nullptr && y->p != nullptr &&
         (out_mode == OUT_NORMAL) && !x.blk && !y->blk && (!res || !res->blk)) {
         // the same layer in launches of launch_group images (slices of the NHWC tensors; results are per image, hence identical)
@@ -332,6 +333,12 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
     p.res_cstride = res ? res->c : 0;
     p.y_cstride = y_cstride ? y_cstride : y->c;
     p.y_coff = y_coff;
+    if (short_l != nullptr) {
+        if (short_y == nullptr || short_l->cin != L.cin || short_l->cout != L.cout || short_l->cfg.bn != L.cfg.bn || short_l->cfg.ck != L.cfg.ck ||
+            short_l->ks != 2 || short_l->stride != 2 || short_y->c != L.cout || short_y->h != y->h || short_y->w != y->w)
+            return locr_fail(eng, "fused shortcut: layer mismatch", L.name.c_str());
+        p.wpk2 = short_l->wpk; p.bias2 = short_l->bias; p.y2 = short_y->p; p.y2_cstride = short_y->c;
+    }
     if (x.c != L.cin) return locr_fail(eng, "conv input channels mismatch", L.name.c_str());
     if (x.p == nullptr || y->p == nullptr) return 0;  // dry run (workspace sizing)
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -356,14 +363,17 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
         HIPCHK(hipEventRecord(e1, st));
         eng->conv_events.push_back({e0, e1});
         const double px = flat ? (double)p.pix_limit : (double)p.N * p.Ho * p.Wo;
-        eng->conv_flops.push_back(L.alg_flop_per_px > 0 ? px * L.alg_flop_per_px : 2.0 * px * L.ks * L.ks * L.cin * L.cout);
+        eng->conv_flops.push_back((L.alg_flop_per_px > 0 ? px * L.alg_flop_per_px : 2.0 * px * L.ks * L.ks * L.cin * L.cout) +
+                                  (short_l ? 2.0 * px * 4 * short_l->cin * short_l->cout : 0.0));
         // algorithmic HBM bytes: input once + output once (+ residual) + weights once
         double in_elems = (double)x.elems();
         if (x.n_src > 1) { in_elems = 0; for (int k = 0; k < x.n_src; ++k) in_elems += (double)x.n * (x.h >> x.xs_shift[k]) * (x.w >> x.xs_shift[k]) * x.src_c(k); }
-        eng->conv_bytes.push_back(2.0 * (in_elems + px * (out_mode == OUT_CONVT && p.fuse_w ? 4.0 : (double)L.cout) * (out_mode == OUT_UPSAMPLE ? (double)(1 << (2 * up_shift)) : (out_mode == OUT_POOL ? 0.25 : 1.0)) + (res ? px * (double)L.cout / (double)(1 << (2 * res_shift)) : 0.0) + (double)L.ks * L.ks * L.cin * L.cout));
-        eng->conv_names.push_back(L.name);
+        eng->conv_bytes.push_back(2.0 * (in_elems + px * (out_mode == OUT_CONVT && p.fuse_w ? 4.0 : (double)L.cout) * (out_mode == OUT_UPSAMPLE ? (double)(1 << (2 * up_shift)) : (out_mode == OUT_POOL ? 0.25 : 1.0)) + (res ? px * (double)L.cout / (double)(1 << (2 * res_shift)) : 0.0) + (double)L.ks * L.ks * L.cin * L.cout +
+                                         (short_l ? px * (double)short_l->cout + 4.0 * short_l->cin * short_l->cout : 0.0)));
+        eng->conv_names.push_back(short_l ? L.name + "+short" : L.name);
         std::string kname = use_pw ? (L.cin == 64 ? "conv_pw_kernel<64>" : "conv_pw_kernel<128>") : conv_kernel_name(cfg);
         if (use_ring) kname = conv_ring_kernel_name(p, eng->ring_orient);
+        if (short_l) { const size_t pos = kname.rfind(",0,2>"); if (pos != std::string::npos) kname.replace(pos, 5, ",5,2>"); }   // the fused-shortcut instantiation
         if (out_mode == OUT_POOL && !use_ring) { const size_t pos = kname.rfind(",3,4>"); if (pos != std::string::npos) kname.replace(pos, 5, ",4,4>"); }  // the fused-pool instantiation
         eng->conv_kernels.push_back(kname);
     }
@@ -427,11 +437,17 @@ static int det_forward_sub(lumina_ocr* eng, const uint8_t* pages, int B, int H, 
             const bool blk = i == 0 && eng->blocked_layout && eng->keep_taps == 0 && eng->conv_ring && !dry &&
                              conv_takes_big(eng, D[p + ".conv0"], B, x.h, x.w, false) && conv_takes_big(eng, D[p + ".conv1"], B, x.h, x.w, false);
             y.blk = blk;
-            RUN(eng_run_conv(eng, D[p + ".conv0"], x, &y, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st));
+            // stages 1-3, first block: conv0 (3x3 / s2) and the vd shortcut (2x2 / s2) read the same input — one launch computes both
+            const ConvLayer& c0 = D[p + ".conv0"];
+            const bool fuse_sc = eng->fuse_short && i > 0 && j == 0 && x.h % 2 == 0 && x.w % 2 == 0 && c0.cfg.bn == 64 && c0.cfg.ck == 16 && c0.cfg.nw == 4 &&
+                                 D[p + ".short"].cfg.bn == 64 && D[p + ".short"].cfg.ck == 16;
             Tensor4 sc = x;
-            if (j == 0) {
-                sc = ws_tensor(eng, B, y.h, y.w, chs[i]);
-                RUN(eng_run_conv(eng, D[p + ".short"], x, &sc, nullptr, 0, OUT_NORMAL, 0, 0, 0, i == 0, st));
+            if (j == 0) sc = ws_tensor(eng, B, y.h, y.w, chs[i]);
+            if (fuse_sc) {
+                RUN(eng_run_conv(eng, c0, x, &y, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st, nullptr, &D[p + ".short"], &sc));
+            } else {
+                RUN(eng_run_conv(eng, c0, x, &y, nullptr, 0, OUT_NORMAL, 0, 0, 0, false, st));
+                if (j == 0) RUN(eng_run_conv(eng, D[p + ".short"], x, &sc, nullptr, 0, OUT_NORMAL, 0, 0, 0, i == 0, st));
             }
             Tensor4 o = ws_tensor(eng, B, y.h, y.w, chs[i]);
             o.blk = blk && j == 0;

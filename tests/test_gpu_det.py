@@ -225,6 +225,34 @@ def test_fpn_p2_composed_with_its_lateral(engine, det_weights, dense_det_weights
         engine.set_option("conv_big_min", 1024)
 
 
+@pytest.mark.parametrize("shape", [(2, 250, 200), (1, 447, 901), (3, 96, 130), (1, 1000, 330)], ids=lambda s: "b%d_%dx%d" % s)
+def test_fused_block_entry_shortcut_is_bit_identical(engine, any_det_weights, shape):
+    """Option fuse_short (default): in stages 1-3 the block entry's 3x3 / stride-2 conv0 kernel also computes the block's 2x2 /
+    stride-2 vd shortcut from the halo it staged — the shortcut's taps are taps (1,1) .. (2,2) of the 3x3 window — with its own
+    accumulators, in the separate kernel's (chunk, tap) order: every tap downstream must be bit-identical, and the launch list
+    must show the fused instantiation instead of the 2x2 / s2 kernel."""
+    b, h, w = shape
+    pages = torch.from_numpy(_pages(b, h, w, 83)).cuda()
+    engine.load_det(any_det_weights)
+    try:
+        engine.set_option("fuse_short", 0)
+        ref = _forward_all(engine, pages)
+        engine.set_option("fuse_short", 1)
+        engine.conv_timing_detail()
+        engine.set_option("time_convs", 1)
+        a = _forward_all(engine, pages)
+        rows = engine.conv_timing_detail()
+    finally:
+        engine.set_option("fuse_short", 1)
+        engine.set_option("time_convs", 0)
+    names = [n for n, *_ in rows]
+    kerns = [k for _, k, *_ in rows]
+    assert sum(k == "conv_mfma_kernel<3,2,64,16,32,4,5,2>" for k in kerns) == 3 and not any(k.startswith("conv_mfma_kernel<2,2,") for k in kerns), kerns
+    assert "s1.b0.conv0+short" in names and "s1.b0.short" not in names
+    _assert_same(a, ref, "fused shortcut")
+    assert np.array_equal(a["prob"], ref["prob"])
+
+
 def test_grouped_quarter_resolution_tail_is_invisible(engine, any_det_weights):
     """Option tail_group: the lateral in2 -> p2 -> head.conv1 -> DBHead tail section runs in groups of pages inside one forward
     (producer -> consumer locality in the Infinity Cache; the 256-channel lateral exists for one group only): launch order only."""
