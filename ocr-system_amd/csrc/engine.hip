@@ -729,17 +729,19 @@ static int rec_forward_sub(lumina_ocr* eng, const uint8_t* crops, const int* wid
         Tensor4 e1{};
         if (!fused_mb || dry) e1 = ws_tensor(eng, N, x.h, x.w, cp16(B.exp));   // (dry run sizes the arena for the unfused path too)
         Tensor4 d = ws_tensor(eng, N, ho, x.w, cp16(B.exp));
+        float* pool = B.se ? static_cast<float*>(eng_ws_alloc(eng, (size_t)N * mb_strips(x.w) * d.c * sizeof(float))) : nullptr;
         if (fused_mb) {
-            mp.x = x.p; mp.d = d.p;
+            mp.x = x.p; mp.d = d.p; mp.pool = pool;   // squeeze-excite blocks: the pooled sums leave with the tile (the tensor is not read again for them)
             if (!dry && x.p && d.p) LAUNCH("mbconv", mbconv_launch(mp, B.k, B.stride_h, st));
         } else {
             RUN(eng_run_conv(eng, B.expand, x, &e1, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
             LAUNCH("dwconv", dwconv_launch(e1.p, B.dw.w, B.dw.bias, d.p, N, e1.h, e1.w, e1.c, B.k, B.stride_h, B.act, st));
+            if (B.se) LAUNCH("se_pool", se_pool_launch(d.p, pool, N, d.h, d.w, d.c, st));   // the same sums in the same order
         }
         const bf16_t* se_gate_ptr = nullptr;
         if (B.se) {
             bf16_t* gate = static_cast<bf16_t*>(eng_ws_alloc(eng, (size_t)N * d.c * sizeof(bf16_t)));
-            LAUNCH("se_gate", se_gate_launch(d.p, B.sel.w1, B.sel.b1, B.sel.w2, B.sel.b2, gate, N, d.h * d.w, d.c, B.sel.mid, st));
+            LAUNCH("se_fc", se_fc_launch(pool, mb_strips(d.w), B.sel.w1, B.sel.b1, B.sel.w2, B.sel.b2, gate, N, d.h * d.w, d.c, B.sel.mid, st));
             se_gate_ptr = gate;   // the scaling itself is fused into the project conv's operand staging
         }
         Tensor4 o = ws_tensor(eng, N, d.h, d.w, cp16(B.cout));

@@ -95,10 +95,15 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
         }
         __syncthreads();
         // ---------------- phase 2: depthwise K x K, stride (SH, 1), from the LDS tile ----------------
-        const int items2 = p.Ho * (MB_TW / XG) * cg;
-        for (int i = tid; i < items2; i += 256) {
-            const int c8 = i % cg;
-            const int t = i / cg;
+        // thread (pg, c8) owns channel group c8 and walks the pixel groups t = pg, pg + groups, ... (the summation order of the
+        // squeeze-excite pooling, mbconv.h)
+        const int groups = 256 / cg, pg = tid / cg, c8_fixed = tid - pg * cg;
+        float psum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int t = pg; t < p.Ho * (MB_TW / XG) && pg < groups; t += groups) {
+            // the channel group is the same in every iteration, but the compiler must not know: it would hoist the group's bias and
+            // depthwise weights out of the loop (+58 registers: the kernel drops from three resident workgroups per CU to two, +24 % time)
+            int c8 = c8_fixed;
+            asm volatile("" : "+v"(c8));
             const int xg = t % (MB_TW / XG), oy = t / (MB_TW / XG);
             const int ox0 = xg * XG;  // strip-local output column; tile column ox0 + j is image column x0 + ox0 - PAD + j
             if (x0 + ox0 >= p.W) continue;
@@ -135,9 +140,65 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
                 if (x0 + ox0 + o >= p.W) break;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) a[o][j] = apply_act(a[o][j] + bb[j], ACT);
-                *reinterpret_cast<uint4*>(yrow + (size_t)o * expc) = pack8(a[o]);
+                const uint4 v = pack8(a[o]);
+                *reinterpret_cast<uint4*>(yrow + (size_t)o * expc) = v;
+                if (p.pool != nullptr) {   // pooled sum of the values as stored
+                    float f[8];
+                    unpack8(v, f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) psum[j] += f[j];
+                }
             }
         }
+        if (p.pool != nullptr) {   // (uniform branch) groups' sums -> LDS (the tile is dead) -> one fixed-order sum per channel
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem);
+            if (pg < groups) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[pg * expc + c8_fixed * 8 + j] = psum[j];
+            }
+            __syncthreads();
+            for (int c = tid; c < expc; c += 256) {
+                float s = 0.f;
+                for (int g = 0; g < groups; ++g) s += red[g * expc + c];
+                p.pool[((size_t)n * strips_x + (x0 / MB_TW)) * expc + c] = s;
+            }
+        }
+    }
+}
+
+// the same sums from a stored tensor (the unfused expand + depthwise path): one workgroup per (crop, strip), identical order
+__global__ __launch_bounds__(256) void se_pool_kernel(const bf16_t* d, float* pool, int N, int Ho, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int XG = 4;
+    const int tid = threadIdx.x, cg = C >> 3, groups = 256 / cg, pg = tid / cg, c8 = tid - pg * cg;
+    const int strips_x = (W + MB_TW - 1) / MB_TW;
+    const int n = blockIdx.x / strips_x, x0 = (blockIdx.x - n * strips_x) * MB_TW;
+    float psum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = pg; t < Ho * (MB_TW / XG) && pg < groups; t += groups) {
+        const int xg = t % (MB_TW / XG), oy = t / (MB_TW / XG);
+        const int ox0 = xg * XG;
+        if (x0 + ox0 >= W) continue;
+        const bf16_t* yrow = d + (((size_t)n * Ho + oy) * W + x0 + ox0) * C + c8 * 8;
+#pragma unroll
+        for (int o = 0; o < XG; ++o) {
+            if (x0 + ox0 + o >= W) break;
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(yrow + (size_t)o * C), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) psum[j] += f[j];
+        }
+    }
+    float* red = reinterpret_cast<float*>(smem);
+    if (pg < groups) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[pg * C + c8 * 8 + j] = psum[j];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int g = 0; g < groups; ++g) s += red[g * C + c];
+        pool[((size_t)n * strips_x + (x0 / MB_TW)) * C + c] = s;
     }
 }
 
@@ -167,6 +228,13 @@ bool mbconv_supported(const MbParams& p, int k, int sh) {
 size_t mbconv_lds_bytes(const MbParams& p, int k) {
     const int ew = MB_TW + 2 * (k / 2), pitch = p.expc * 2 + 16;
     return (((size_t)p.H * ew * pitch + 15) & ~(size_t)15) + ((size_t)k * k * p.expc + p.expc) * sizeof(float);
+}
+
+hipError_t se_pool_launch(const bf16_t* d, float* pool, int N, int Ho, int W, int C, hipStream_t st) {
+    if (C % 8 != 0 || C / 8 > 256 || C < 8) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(256 / (C / 8)) * C * sizeof(float);
+    hipLaunchKernelGGL(se_pool_kernel, dim3(N * mb_strips(W)), dim3(256), lds, st, d, pool, N, Ho, W, C);
+    return hipGetLastError();
 }
 
 hipError_t mbconv_launch(const MbParams& p, int k, int sh, hipStream_t st) {

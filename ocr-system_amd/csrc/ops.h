@@ -9,10 +9,11 @@ hipError_t maxpool_launch(const bf16_t* x, bf16_t* y, int N, int H, int W, int C
 hipError_t dwconv_launch(const bf16_t* x, const bf16_t* w, const float* bias, bf16_t* y, int N, int H, int W, int C, int k,
                          int sh, int act, hipStream_t st);
 
-// squeeze-excite gate: s = hsigmoid(W2 * relu(W1 * mean_hw(x) + b1) + b2), all stored values bf16.
+// squeeze-excite gate: s = hsigmoid(W2 * relu(W1 * mean_hw(x) + b1) + b2), all stored values bf16, from the per-strip pooled sums
+// pool [N][strips][C] (mbconv.h: written by the fused expand + depthwise kernel or by se_pool_launch).
 // w1: [mid][C] bf16, w2: [C][mid] bf16 (row-major, unpadded mid), gate: [N][C] bf16
-hipError_t se_gate_launch(const bf16_t* x, const bf16_t* w1, const float* b1, const bf16_t* w2, const float* b2, bf16_t* gate,
-                          int N, int HW, int C, int mid, hipStream_t st);
+hipError_t se_fc_launch(const float* pool, int strips, const bf16_t* w1, const float* b1, const bf16_t* w2, const float* b2, bf16_t* gate,
+                        int N, int HW, int C, int mid, hipStream_t st);
 // y = bf16(x * gate[n, c])
 hipError_t se_scale_launch(const bf16_t* x, const bf16_t* gate, bf16_t* y, int N, int HW, int C, hipStream_t st);
 

@@ -122,32 +122,18 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* x, const bf16
     }
 }
 
-// ------------------------------------------------------------------ squeeze-excite gate (one block per image)
-__global__ __launch_bounds__(256) void se_gate_kernel(const bf16_t* x, const bf16_t* w1, const float* b1, const bf16_t* w2,
-                                                      const float* b2, bf16_t* gate, int HW, int C, int mid) {
-    extern __shared__ float sm[];  // [256/cg][C] partial sums, then mean[C], hid[mid]
-    const int n = blockIdx.x, tid = threadIdx.x, cg = C >> 3;
-    const int groups = 256 / cg;  // pixel groups
-    const int c8 = tid % cg, pg = tid / cg;
-    float a[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = 0.f;
-    if (pg < groups) {
-        for (int px = pg; px < HW; px += groups) {
-            float f[8];
-            unpack8(*reinterpret_cast<const uint4*>(x + ((size_t)n * HW + px) * C + c8 * 8), f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] += f[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sm[pg * C + c8 * 8 + j] = a[j];
-    }
-    __syncthreads();
-    float* mean = sm + groups * C;
+// ------------------------------------------------------------------ squeeze-excite gate from the pooled sums (one block per crop)
+// pool [N][strips][C]: per-strip sums of the depthwise output, written by the fused expand + depthwise kernel's epilogue (mbconv.hip) or by
+// se_pool_kernel — the tensor itself is not read again (the nine full passes over it per recogniser forward were 0.9 ms of a 64-page step).
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* pool, int strips, const bf16_t* w1, const float* b1, const bf16_t* w2,
+                                                    const float* b2, bf16_t* gate, int HW, int C, int mid) {
+    extern __shared__ float sm[];  // mean[C], hid[mid]
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float* mean = sm;
     float* hid = mean + C;
     for (int c = tid; c < C; c += 256) {
         float s = 0.f;
-        for (int g = 0; g < groups; ++g) s += sm[g * C + c];
+        for (int g = 0; g < strips; ++g) s += pool[((size_t)n * strips + g) * C + c];
         mean[c] = bf16_to_f32(f32_to_bf16(s / (float)HW));
     }
     __syncthreads();
@@ -443,11 +429,9 @@ hipError_t dwconv_launch(const bf16_t* x, const bf16_t* w, const float* bias, bf
     return hipGetLastError();
 }
 
-hipError_t se_gate_launch(const bf16_t* x, const bf16_t* w1, const float* b1, const bf16_t* w2, const float* b2, bf16_t* gate,
-                          int N, int HW, int C, int mid, hipStream_t st) {
-    const int cg = C / 8, groups = 256 / cg;
-    const size_t lds = ((size_t)groups * C + C + mid) * sizeof(float);
-    hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), lds, st, x, w1, b1, w2, b2, gate, HW, C, mid);
+hipError_t se_fc_launch(const float* pool, int strips, const bf16_t* w1, const float* b1, const bf16_t* w2, const float* b2, bf16_t* gate,
+                        int N, int HW, int C, int mid, hipStream_t st) {
+    hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), ((size_t)C + mid) * sizeof(float), st, pool, strips, w1, b1, w2, b2, gate, HW, C, mid);
     return hipGetLastError();
 }
 
