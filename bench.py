@@ -27,7 +27,8 @@ sys.path.insert(0, str(ROOT))
 
 PAGES_PER_RANK = 64
 A4_H, A4_W = 2339, 1654
-MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (bf16 and fp16 dense alike)
+HBM_PEAK_GBS = 8000.0                  # same guide: HBM3E spec peak
 PMC_FILE = "r02_pmc_hbm.json"          # {"source_sha16": {file: sha}, "kernels": {name: {"hbm_bytes_per_launch": ...}}} (tools/pmc_to_json.py)
 
 
@@ -152,6 +153,115 @@ class DryPipeline:
             yield self.gather.finish(self.gather.submit(counts, quads, sc, text, length, sc)), None
 
 
+class H2DFeed:
+    """Batches that start in pinned host memory (value_with_h2d): a copy stream fills one of three device buffers per step, the copy
+    of step k+1 is issued when step k is handed out, so it runs under step k's kernels; events order copies and consumers."""
+
+    def __init__(self, torch, pages_dev, device):
+        self.torch = torch
+        self.host = torch.empty(pages_dev.shape, dtype=pages_dev.dtype, pin_memory=True)
+        self.host.copy_(pages_dev)
+        self.bufs = [torch.empty_like(pages_dev) for _ in range(3)]
+        self.copy_stream = torch.cuda.Stream(device)
+        self.device = device
+
+    def batches(self, k):
+        torch = self.torch
+        cur = torch.cuda.current_stream(self.device)
+        copied = [None] * 3        # event: the copy into buffer i has landed
+        released = []              # released[j]: recorded on the compute stream when batch j+1 was asked for (batch j's reads are enqueued)
+
+        def issue(j):
+            b = j % 3
+            with torch.cuda.stream(self.copy_stream):
+                if j >= 3:                                  # buffer b was read by batch j-3
+                    self.copy_stream.wait_event(released[j - 3])
+                self.bufs[b].copy_(self.host, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+            copied[b] = ev
+
+        issue(0)
+        for j in range(k):
+            if j + 1 < k:
+                issue(j + 1)
+            cur.wait_event(copied[j % 3])
+            yield self.bufs[j % 3]
+            ev = torch.cuda.Event()
+            ev.record(cur)                                  # everything that reads batch j is enqueued by now (run_many asks for j+1 after submitting j)
+            released.append(ev)
+
+
+def bench_stage(args):
+    """--config 2 / 3 / 5: one stage of the path on its BASELINE configuration, inputs resident in HBM, one JSON line with its own roofline."""
+    import torch
+    import numpy as np
+    from lumina_ocr import arch, synth
+    from lumina_ocr.engine import Engine
+    rank = int(os.environ.get("RANK", 0))
+    if int(os.environ.get("WORLD_SIZE", 1)) != 1 or args.gpus != 1:
+        print("bench.py: --config %d is a single-GPU stage measurement" % args.config, file=sys.stderr)
+        return 2
+    torch.cuda.set_device(0)
+    eng = Engine(0)
+    if args.config == 2:
+        det_w = arch.make_det_weights(1234)
+        eng.load_det(det_w)
+        n = 32
+        eng.set_option("det_sub_batch", n)
+        base = np.stack([synth.synth_page(1024, 1024, 1234 + k, n_lines=40)[0] for k in range(8)])
+        x = torch.from_numpy(np.concatenate([base] * 4)).cuda()
+        out = [None]
+        def step():
+            out[0] = eng.det_forward(x, out=out[0]) if out[0] is not None else eng.det_forward(x)
+        unit, metric, dtype = "pages/sec", "pages/sec DBNet-R18vd detection only, 1024x1024 pages", "bf16"
+        workload = "DBNet-R18 detection only, batch=32 1024x1024 synthetic pages, bf16 (BASELINE configs[1]): u8 pages in HBM -> normalise -> backbone + FPN + head -> bf16 probability map"
+        bound, data = "mfma", "synthetic (rendered text pages, seeded); weights random-init (seeded) + hand-set text path"
+    else:
+        n = 512
+        rng = np.random.default_rng(4321 if args.config == 3 else 777)
+        base = np.stack([synth.synth_crop(rng)[0] for _ in range(64)])
+        x = torch.from_numpy(np.concatenate([base] * 8)).cuda()
+        if args.config == 3:
+            eng.load_rec(arch.make_rec_weights(4321, code_path=True))
+            fwd = eng.rec_forward
+            metric, dtype = "crops/sec CRNN-MobileNetV3 + BiLSTM + CTC greedy, 32x320 crops", "bf16"
+            workload = "CRNN-MobileNetV3 recognition + CTC greedy, batch=512 32x320 line crops (BASELINE configs[2]): u8 crops in HBM -> class ids + lengths + scores"
+            bound = "hbm"
+        else:
+            cs = arch.devanagari_charset()
+            eng.load_svtr(arch.make_svtr_weights(num_classes=len(cs), variant="base", dtype="f16"))
+            fwd = eng.svtr_forward
+            metric, dtype = "crops/sec SVTR-Base (Hindi dictionary) + CTC greedy, 32x320 crops", "f16"
+            workload = "SVTR-base multilingual (Devanagari dictionary, %d classes), fp16 MFMA, batch=512 32x320 crops (BASELINE configs[4], one GPU)" % len(cs)
+            bound = "hbm"
+        def step():
+            idx, prob = fwd(x)
+            eng.ctc_decode(idx, prob)
+        unit, data = "crops/sec", "synthetic (rendered random strings, seeded); weights random-init (seeded), no checkpoints or dictionaries offline"
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    eng.conv_timing_detail()
+    eng.set_option("time_convs", 1)
+    step()
+    rows = eng.conv_timing_detail()
+    eng.set_option("time_convs", 0)
+    roof = roofline_from_rows(rows, bound, stage_ms=el / args.steps * 1e3)
+    if rank == 0:
+        print(json.dumps({"metric": metric, "value": round(n * args.steps / el, 2), "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+                          "data": data, "config": {"workload": workload, "batch": n, "input": "resident in HBM when the timed region starts"},
+                          "roofline": roof}), flush=True)
+    eng.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,7 +270,11 @@ def main():
     ap.add_argument("--pages", type=int, default=PAGES_PER_RANK, help="pages per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--det-sub-batch", type=int, default=64, help="pages per detector launch group (64: the whole step; +2 %% over 16)")
-    ap.add_argument("--deskew", action="store_true", help="also run the reference's default-on de-skew step (OpenCV there; off here: see config.deskew)")
+    ap.add_argument("--deskew", action="store_true", help="run the reference's default-on de-skew step inside the MAIN timed loop too (by default it is measured by a second loop and reported as value_with_deskew)")
+    ap.add_argument("--config", type=int, default=4, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs[n-1]: 4 = end-to-end det+rec on A4 pages (the metric; default), 2 = DBNet-R18 detection only, batch 32 of "
+                         "1024x1024 pages, 3 = CRNN-MV3 + CTC greedy on 512 line crops, 5 = SVTR-Base fp16 + Hindi dictionary on 512 crops")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary timed loops of config 4 (value_with_deskew, value_with_h2d)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal, only with --dry-engine")
     ap.add_argument("--dry-engine", action="store_true", help="no GPU, fake recogniser outputs: rehearses launcher + gather on CPU")
     ap.add_argument("--seed-rank", type=int, default=-1, help="(tests) generate the pages of THIS rank (page seed = 2024 + 1000 * rank) whatever RANK says")
@@ -176,6 +290,10 @@ def main():
     # N > 1 without a launcher: become the launcher (before anything touches the GPU)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))
+    if args.config != 4:
+        if args.dry_engine or args.share_device:
+            ap.error("--config 2 / 3 / 5 are single-stage measurements on the real engine")
+        return bench_stage(args)
 
     import torch
     import torch.distributed as dist
@@ -254,6 +372,39 @@ def main():
         per_page = [pg["texts"] for pg in dets.pages()] if hasattr(dets, "pages") else [list(d.texts) for d in dets]
         digests = ["%08x" % zlib.crc32("\n".join(t).encode("utf-8")) for t in per_page]
 
+    # ---- secondary figures of the same run (the exclusions of the headline, measured instead of described) ----
+    secondary = {}
+    if not dry and not args.no_secondary:
+        def timed(fn):
+            fence()
+            t = time.perf_counter()
+            fn()
+            fence()
+            el = time.perf_counter() - t
+            if distributed:
+                tt = torch.tensor([el], dtype=torch.float64, device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            return round(args.pages * world * args.steps / el, 2)
+
+        if not args.deskew:   # the reference provider's default: OCR_APPLY_DESKEW = true (backend/config.py:85)
+            def with_deskew():
+                for _ in pipe.run_many((pages for _ in range(args.steps)), deskew=True):
+                    pass
+            for _ in pipe.run_many((pages for _ in range(2)), deskew=True):   # (first use uploads its tables)
+                pass
+            secondary["value_with_deskew"] = timed(with_deskew)
+        # pages start in PINNED HOST memory: every step's 64 x 11.6 MB cross PCIe inside the timed region (copy stream, three device
+        # buffers: the copy of step k+2 runs under the compute of step k+1)
+        feed = H2DFeed(torch, pages, device)
+        def with_h2d():
+            for _ in pipe.run_many(feed.batches(args.steps), deskew=args.deskew):
+                pass
+        for _ in pipe.run_many(feed.batches(2), deskew=args.deskew):
+            pass
+        secondary["value_with_h2d"] = timed(with_h2d)
+        del feed
+
     roofline = None
     if not dry:
         roofline = measure_roofline(eng, pipe, pages)
@@ -282,10 +433,15 @@ def main():
                        "input": "pages pre-decoded (uint8 RGB) and resident in HBM when the timed region starts",
                        "outside_timed_region": "image decode, host->device copy, JPEG hand-off of the processed page (2.5 ms per 64 pages on the device)",
                        "det_sub_batch": args.det_sub_batch,
-                       "deskew": ("on" if args.deskew else "off: not part of det+rec; the reference's deskew needs OpenCV and is a no-op without it (image_preprocessing.py:383-385); "
-                                  "on the device it costs ~12 ms per 64 pages (DESIGN.md), run with --deskew to include it")},
+                       "deskew": ("on" if args.deskew else "off in `value` (det+rec as BASELINE.json names it; the reference's own deskew is a no-op without OpenCV, "
+                                  "image_preprocessing.py:383-385); `value_with_deskew` = the same steps with the provider's default-on de-skew (backend/config.py:85) on the device")},
             "roofline": roofline,
         }
+        if secondary:
+            out.update(secondary)
+            out["secondary_note"] = ("same process, same pages, %d steps each after the main loop: value_with_deskew = + the reference's default-on de-skew step; "
+                                     "value_with_h2d = pages start in pinned host memory and are copied to the device inside the timed region "
+                                     "(image DECODE stays outside: the boundary hands over decoded uint8 pages)" % args.steps)
         if dry:
             out["data"] = "DRY ENGINE (CPU rehearsal of the launcher and the gather; not a measurement)"
             out["value"] = None
@@ -310,12 +466,43 @@ def _sha16(path):
     return hashlib.sha256(Path(path).read_bytes()).hexdigest()[:16]
 
 
+def roofline_from_rows(rows, bound, stage_ms=None):
+    """rows: (layer, kernel instantiation, ms, GFLOP, algorithmic MB) per timed launch of one step -> the roofline object of the kernel
+    with the largest summed time.  bound "mfma": algorithmic FLOP / time against the dense MFMA peak; "hbm": algorithmic bytes / time
+    against the HBM peak (the recogniser paths: short-K products and depthwise convolutions, < 100 FLOP per byte)."""
+    by_kernel = {}
+    for _, kern, ms, gf, mb in rows:
+        a = by_kernel.setdefault(kern, [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += gf; a[3] += mb
+    dom = max(by_kernel, key=lambda k: by_kernel[k][1])
+    dn, dms, dgf, dmb = by_kernel[dom]
+    tot_ms = sum(a[1] for a in by_kernel.values())
+    out = {"bound": bound, "kernel": dom, "launches_per_step": dn, "avg_launch_us": round(dms / dn * 1e3, 1), "share_of_timed_launches": round(dms / tot_ms, 3),
+           "flop_per_launch": dgf / dn * 1e9, "algorithmic_bytes_per_launch": dmb / dn * 1e6}
+    if bound == "mfma":
+        ach = dgf / dms
+        out.update(achieved=round(ach, 2), peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4))
+    else:
+        ach = dmb / dms   # MB / ms == GB/s
+        out.update(achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                   mfma_tflops=round(dgf / dms, 2))
+        if dom.startswith("mbconv_kernel"):
+            out["limiter"] = "vector ALU: the depthwise K x K convolution is fp32 FMA work (25 taps per output for K = 5), not bytes and not MFMA (PMC, profiles/r01_c_pmc_sq_rec_summary.txt)"
+    out["traffic"] = None
+    out["all_timed_launches"] = {"launches_per_step": len(rows), "ms_per_step": round(tot_ms, 3), "tflops": round(sum(a[2] for a in by_kernel.values()) / tot_ms, 2),
+                                 "algorithmic_gb_per_s": round(sum(a[3] for a in by_kernel.values()) / tot_ms, 1)}
+    if stage_ms is not None:
+        out["all_timed_launches"]["stage_ms_per_step"] = round(stage_ms, 3)
+    return out
+
+
 def measure_roofline(eng, pipe, pages):
     """HIP events on the launch stream around every conv launch of one extra step (outside the timed region)."""
     eng.set_option("time_convs", 1)
     pipe.finish(pipe.submit_recognize(*pipe.submit_detect(pages)))
     rows = eng.conv_timing_detail()          # (layer, kernel instantiation, ms, GFLOP, algorithmic MB) per launch
     eng.set_option("time_convs", 0)
+    rows = [r for r in rows if r[1].startswith("conv_")]   # the conv family (the recogniser's other launches are timed too: --config 3)
     by_kernel = {}
     for _, kern, ms, gf, mb in rows:
         a = by_kernel.setdefault(kern, [0, 0.0, 0.0, 0.0])
@@ -344,7 +531,8 @@ def measure_roofline(eng, pipe, pages):
     return {"bound": "mfma", "kernel": dom, "launches_per_step": dn, "avg_launch_us": round(dms / dn * 1e3, 1),
             "flop_per_launch": dgf / dn * 1e9, "algorithmic_bytes_per_launch": dmb / dn * 1e6,
             "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
+            "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_over_algorithmic": (round(traffic / (dmb / dn * 1e6), 3) if traffic else None), "traffic_note": note,
             "family": {"kernel": "all conv launches (conv_ring_kernel + conv_mfma_kernel instantiations + conv_pw_kernel)", "launches_per_step": len(rows),
                        "ms_per_step": round(fam_ms, 3), "achieved": round(fam_gf / fam_ms, 2),
                        "frac": round(fam_gf / fam_ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}}

@@ -382,6 +382,21 @@ int eng_run_conv(lumina_ocr* eng, const ConvLayer& L, const Tensor4& x, Tensor4*
 
 #define RUN(expr) do { if ((expr) != 0) return 1; } while (0)
 
+// option time_convs: HIP events on the launch stream around ONE launch of the recogniser paths too (bench.py --config 3 / 5);
+// flop / bytes are the launch's algorithmic work (operands and results once)
+struct LaunchTimer {
+    lumina_ocr* eng; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
+    LaunchTimer(lumina_ocr* e, hipStream_t s, bool enabled) : eng(e), st(s), on(enabled && e->time_convs) {
+        if (on) { on = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventRecord(e0, st) == hipSuccess; }
+    }
+    void done(const std::string& layer, const std::string& kernel, double flop, double bytes) {
+        if (!on || hipEventRecord(e1, st) != hipSuccess) return;
+        eng->conv_events.push_back({e0, e1});
+        eng->conv_flops.push_back(flop); eng->conv_bytes.push_back(bytes);
+        eng->conv_names.push_back(layer); eng->conv_kernels.push_back(kernel);
+    }
+};
+
 static void tap(lumina_ocr* eng, const char* name, const Tensor4& t) { if (eng->keep_taps && t.p) eng->taps[name] = t; }
 
 // ------------------------------------------------------------------------------ det forward
@@ -732,7 +747,13 @@ static int rec_forward_sub(lumina_ocr* eng, const uint8_t* crops, const int* wid
         float* pool = B.se ? static_cast<float*>(eng_ws_alloc(eng, (size_t)N * mb_strips(x.w) * d.c * sizeof(float))) : nullptr;
         if (fused_mb) {
             mp.x = x.p; mp.d = d.p; mp.pool = pool;   // squeeze-excite blocks: the pooled sums leave with the tile (the tensor is not read again for them)
-            if (!dry && x.p && d.p) LAUNCH("mbconv", mbconv_launch(mp, B.k, B.stride_h, st));
+            if (!dry && x.p && d.p) {
+                LaunchTimer tm(eng, st, true);
+                LAUNCH("mbconv", mbconv_launch(mp, B.k, B.stride_h, st));
+                const double opx = (double)N * ho * x.w, ipx = (double)N * x.h * x.w;
+                tm.done("rec.b" + std::to_string(bi) + ".expand+dw", "mbconv_kernel<" + std::to_string(B.k) + "," + std::to_string(B.stride_h) + "," + std::to_string(B.act) + ">",
+                        2.0 * ipx * x.c * mp.expc + 2.0 * opx * B.k * B.k * mp.expc, 2.0 * (ipx * x.c + opx * mp.expc));
+            }
         } else {
             RUN(eng_run_conv(eng, B.expand, x, &e1, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
             LAUNCH("dwconv", dwconv_launch(e1.p, B.dw.w, B.dw.bias, d.p, N, e1.h, e1.w, e1.c, B.k, B.stride_h, B.act, st));
@@ -758,7 +779,11 @@ static int rec_forward_sub(lumina_ocr* eng, const uint8_t* crops, const int* wid
         Tensor4 xp = ws_tensor(eng, N, 1, T, 8 * 96);
         RUN(eng_run_conv(eng, eng->xproj[l], seq, &xp, nullptr, 0, OUT_NORMAL, 0, 0, 0, true, st));
         Tensor4 hs = ws_tensor(eng, N, 1, T, 2 * 96);
-        LAUNCH("lstm", lstm_recurrent_launch(xp.p, eng->whh[l], hs.p, N, T, st));
+        {
+            LaunchTimer tm(eng, st, !dry);
+            LAUNCH("lstm", lstm_recurrent_launch(xp.p, eng->whh[l], hs.p, N, T, st));
+            tm.done("lstm.l" + std::to_string(l), "lstm_kernel", 2.0 * N * T * 2 * 96 * 384, 2.0 * N * T * (768 + 192));
+        }
         tap(eng, l == 0 ? "lstm.l0" : "lstm.l1", hs);
         seq = hs;
     }
@@ -766,8 +791,10 @@ static int rec_forward_sub(lumina_ocr* eng, const uint8_t* crops, const int* wid
         CtcFcParams cp{};
         cp.seq = seq.p; cp.wpk = eng->ctc_wpk; cp.bias = eng->ctc_bias; cp.out_idx = idx; cp.out_prob = prob;
         cp.M = N * T; cp.K = 192; cp.C = eng->num_classes; cp.ntiles = eng->ctc_ntiles;
+        LaunchTimer tm(eng, st, true);
         hipError_t e = ctc_fc_argmax_launch(cp, st);
         if (e != hipSuccess) return locr_fail(eng, "ctc_fc_argmax", hipGetErrorString(e));
+        tm.done("ctc.fc+argmax", "ctc_fc_argmax_kernel<0>", 2.0 * cp.M * cp.K * cp.C, 2.0 * cp.M * cp.K + 8.0 * cp.M + 2.0 * cp.K * cp.C);
     }
     return 0;
 }
@@ -926,8 +953,13 @@ static int run_linear(lumina_ocr* eng, const SvtrLinear& L, const Tensor4& x, Te
     p.zeros = eng->zero_block; p.M = (int)(y->elems() / L.N); p.K = L.K; p.N = L.N; p.act = L.act; p.eps = 1e-6f;
     p.taps = L.taps; p.Cin = L.cin; p.Hin = hin; p.Win = win; p.Tout = hout * wout; p.Wout = wout; p.sh = sh; p.sw = sw;
     if (x.c != L.cin || y->c != L.N) return locr_fail(eng, "svtr linear: channel mismatch", "");
+    LaunchTimer tm(eng, st, true);
     hipError_t e = svtr_gemm_launch(p, eng->svtr.dtype, st);
-    return e == hipSuccess ? 0 : locr_fail(eng, "svtr_gemm", hipGetErrorString(e));
+    if (e != hipSuccess) return locr_fail(eng, "svtr_gemm", hipGetErrorString(e));
+    // algorithmic bytes: the input tensor, the weights, the result and the residual once (a 9-tap gather re-reads its input from cache)
+    tm.done("svtr.linear", svtr_gemm_kernel_name(p, eng->svtr.dtype), 2.0 * p.M * p.K * p.N,
+            2.0 * ((double)x.elems() + (double)p.N * p.K + (double)p.M * p.N + (res && res_mod == 0 ? (double)p.M * p.N : 0.0)));
+    return 0;
 }
 
 static int svtr_forward_sub(lumina_ocr* eng, const uint8_t* crops, const int* widths, int N, int* idx, float* prob, hipStream_t st) {
@@ -957,7 +989,12 @@ static int svtr_forward_sub(lumina_ocr* eng, const uint8_t* crops, const int* wi
         Tensor4 qkv = ws_tensor(eng, N, x.h, x.w, 3 * c);
         RUN(run_linear(eng, B.qkv, x, &qkv, nullptr, 0, 0, 1, 1, 1, 1, 1, 1, dry, st));
         Tensor4 att = ws_tensor(eng, N, x.h, x.w, c);
-        LAUNCH("svtr.attn", svtr_attention_launch(qkv.p, att.p, N, Tk, B.heads, B.gh, B.gw, B.local ? 1 : 0, dt, st));
+        {
+            LaunchTimer tm(eng, st, !dry);
+            LAUNCH("svtr.attn", svtr_attention_launch(qkv.p, att.p, N, Tk, B.heads, B.gh, B.gw, B.local ? 1 : 0, dt, st));
+            const double keys = B.local ? 77.0 : (double)Tk;   // keys a query attends (7 x 11 window / all)
+            tm.done("svtr.attn", std::string("svtr_attn_kernel<") + (dt ? "1>" : "0>"), 4.0 * N * Tk * keys * c, 2.0 * N * Tk * 4.0 * c);
+        }
         Tensor4 x1 = ws_tensor(eng, N, x.h, x.w, c);
         RUN(run_linear(eng, B.proj, att, &x1, x.p, 0, 0, 1, 1, 1, 1, 1, 1, dry, st));        // + residual, LayerNorm 1
         Tensor4 f1 = ws_tensor(eng, N, x.h, x.w, 4 * c);
@@ -976,8 +1013,10 @@ static int svtr_forward_sub(lumina_ocr* eng, const uint8_t* crops, const int* wi
         CtcFcParams cp{};
         cp.seq = seq.p; cp.wpk = M.ctc_wpk; cp.bias = M.ctc_bias; cp.out_idx = idx; cp.out_prob = prob;
         cp.M = N * T; cp.K = M.out_ch; cp.C = M.num_classes; cp.ntiles = M.ctc_ntiles; cp.f16 = dt;
+        LaunchTimer tm(eng, st, true);
         hipError_t e = ctc_fc_argmax_launch(cp, st);
         if (e != hipSuccess) return locr_fail(eng, "svtr ctc_fc_argmax", hipGetErrorString(e));
+        tm.done("svtr.ctc.fc+argmax", std::string("ctc_fc_argmax_kernel<") + (dt ? "1>" : "0>"), 2.0 * cp.M * cp.K * cp.C, 2.0 * cp.M * cp.K + 8.0 * cp.M + 2.0 * cp.K * cp.C);
     }
     return 0;
 }

@@ -19,6 +19,7 @@ struct SvtrGemmParams {
     int taps, Cin, Hin, Win, Tout, Wout, sh, sw;
 };
 hipError_t svtr_gemm_launch(const SvtrGemmParams& p, int dtype, hipStream_t st);
+const char* svtr_gemm_kernel_name(const SvtrGemmParams& p, int dtype);
 // crops u8 [N][32][320][3] (+ optional valid widths) -> normalised 3x3 / stride-2 patches [N * 16 * 160][32]
 hipError_t svtr_im2col_launch(const uint8_t* crops, const int* widths, uint16_t* out, int N, int dtype, hipStream_t st);
 // y[n,x,c] = mean_r x[n,r,x,c]
