@@ -103,6 +103,12 @@ int lumina_ocr_enhance(lumina_ocr_t* h, const uint8_t* img_dev, int n, int heigh
 int lumina_ocr_binarize(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, int adaptive, int threshold, uint8_t* out_dev,
                         void* stream);
 
+/* optimize_for_ocr's optional steps (image_preprocessing.py:225-231; both off by default in the reference's callers):
+ * convert_to_grayscale (:167-169) = PIL convert('L'), written to all three channels of the page; denoise (:160-165) = PIL
+ * MedianFilter(3), per channel, image edge-replicated.  uint8 [n,H,W,3] in and out (denoise: not in place); byte-exact with Pillow. */
+int lumina_ocr_grayscale(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, uint8_t* out_dev, void* stream);
+int lumina_ocr_denoise(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, uint8_t* out_dev, void* stream);
+
 /* deskew (image_preprocessing.py:372-460; on by default in the provider: backend/config.py:85, ocr_service.py:412-417): Canny(50, 150)
  * -> Hough line segments (threshold 100, min length 100, max gap 10) -> median of the segment angles folded into [-45, 45] ->
  * unchanged below 0.5 / above 45 degrees -> cubic affine warp about (W / 2, H / 2) with replicated borders.  The reference does

@@ -360,6 +360,20 @@ int lumina_ocr_binarize(lumina_ocr_t* h, const uint8_t* img_dev, int n, int heig
     return e == hipSuccess ? 0 : locr_fail(h, "binarize", hipGetErrorString(e));
 }
 
+int lumina_ocr_grayscale(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, uint8_t* out_dev, void* stream) {
+    if (!h || !img_dev || !out_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "grayscale", "bad arguments");
+    BIND(h);
+    hipError_t e = grayscale_launch(img_dev, out_dev, n, height, width, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : locr_fail(h, "grayscale", hipGetErrorString(e));
+}
+
+int lumina_ocr_denoise(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, uint8_t* out_dev, void* stream) {
+    if (!h || !img_dev || !out_dev || n <= 0 || height <= 0 || width <= 0 || img_dev == out_dev) return locr_fail(h, "denoise", "bad arguments (not in place)");
+    BIND(h);
+    hipError_t e = median3_launch(img_dev, out_dev, n, height, width, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : locr_fail(h, "denoise", hipGetErrorString(e));
+}
+
 int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, int optimize,
                            uint8_t* out_dev, size_t out_stride, int32_t* sizes_dev, void* stream) {
     if (!h || !pages_dev || !out_dev || !sizes_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "jpeg_encode", "bad arguments");

@@ -15,3 +15,7 @@ hipError_t enhance_launch(const uint8_t* img, uint8_t* tmp, uint8_t* out, unsign
 // binarisation (image_preprocessing.py:175-185 / :462-494): adaptive = 0: L > threshold; 1: Gaussian 11x11 adaptive threshold, C = 2.
 // RGB u8 [N,H,W,3] in, the 0 / 255 value on all three channels out.
 hipError_t binarize_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, int adaptive, int threshold, hipStream_t st);
+// optimize_for_ocr's optional steps (image_preprocessing.py:160-169, :225-231): PIL convert('L') replicated to three channels, and
+// PIL MedianFilter(3) (edge-replicated); RGB u8 [N,H,W,3] in and out, byte-exact with Pillow (tests/golden/preprocess_vectors.npz)
+hipError_t grayscale_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, hipStream_t st);
+hipError_t median3_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, hipStream_t st);

@@ -491,6 +491,60 @@ __global__ __launch_bounds__(256) void binarize_kernel(const uint8_t* img, uint8
 }
 }  // namespace
 
+namespace {
+// ImagePreprocessor.convert_to_grayscale (image_preprocessing.py:167-169) = PIL convert('L'): L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16,
+// written to all three channels (the engine's page format; ImageEnhance on an L image and on its R = G = B replica give the same bytes)
+__global__ __launch_bounds__(256) void grayscale_kernel(const uint8_t* img, uint8_t* out, long long npix) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const uint8_t* s = img + i * 3;
+        const unsigned l = (19595u * s[0] + 38470u * s[1] + 7471u * s[2] + 0x8000u) >> 16;
+        out[i * 3 + 0] = (uint8_t)l; out[i * 3 + 1] = (uint8_t)l; out[i * 3 + 2] = (uint8_t)l;
+    }
+}
+
+// ImagePreprocessor.denoise (:160-165) = PIL ImageFilter.MedianFilter(3): per channel the 5th smallest of the 3x3 neighbourhood, the
+// image extended by replicating its edge pixels (RankFilter expands the image by size // 2 before filtering).  One thread per pixel,
+// all three channels; the nine values go through the 19-exchange median network (min / max only: branch-free).
+__device__ __forceinline__ void mm(int& a, int& b) { const int lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
+__device__ __forceinline__ int median9(int v0, int v1, int v2, int v3, int v4, int v5, int v6, int v7, int v8) {
+    mm(v1, v2); mm(v4, v5); mm(v7, v8); mm(v0, v1); mm(v3, v4); mm(v6, v7); mm(v1, v2); mm(v4, v5); mm(v7, v8);
+    mm(v0, v3); mm(v5, v8); mm(v4, v7); mm(v3, v6); mm(v1, v4); mm(v2, v5); mm(v4, v7); mm(v4, v2); mm(v6, v4); mm(v4, v2);
+    return v4;
+}
+__global__ __launch_bounds__(256) void median3_kernel(const uint8_t* img, uint8_t* out, int H, int W) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uint8_t* base = img + (size_t)blockIdx.z * H * W * 3;
+    int v[3][9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = min(max(y + dy - 1, 0), H - 1);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = min(max(x + dx - 1, 0), W - 1);
+            const uint8_t* s = base + ((size_t)yy * W + xx) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c][dy * 3 + dx] = s[c];
+        }
+    }
+    uint8_t* d = out + (((size_t)blockIdx.z * H + y) * W + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = (uint8_t)median9(v[c][0], v[c][1], v[c][2], v[c][3], v[c][4], v[c][5], v[c][6], v[c][7], v[c][8]);
+}
+}  // namespace
+
+hipError_t grayscale_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, hipStream_t st) {
+    const long long npix = (long long)N * H * W;
+    long long g = (npix + 255) / 256;
+    hipLaunchKernelGGL(grayscale_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, st, img, out, npix);
+    return hipGetLastError();
+}
+
+hipError_t median3_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, hipStream_t st) {
+    hipLaunchKernelGGL(median3_kernel, dim3((W + 63) / 64, (H + 3) / 4, N), dim3(256), 0, st, img, out, H, W);
+    return hipGetLastError();
+}
+
 hipError_t binarize_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, int adaptive, int threshold, hipStream_t st) {
     hipLaunchKernelGGL(binarize_kernel, dim3((W + BZ_TW - 1) / BZ_TW, (H + BZ_TH - 1) / BZ_TH, N), dim3(256), 0, st, img, out, H, W, adaptive, threshold);
     return hipGetLastError();

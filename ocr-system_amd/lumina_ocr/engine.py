@@ -72,6 +72,8 @@ def load_library() -> ctypes.CDLL:
         "lumina_ocr_svtr_num_classes": (i32, [vp]),
         "lumina_ocr_svtr_dtype": (i32, [vp]),
         "lumina_ocr_binarize": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+        "lumina_ocr_grayscale": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+        "lumina_ocr_denoise": (i32, [vp, vp, i32, i32, i32, vp, vp]),
         "lumina_ocr_deskew": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "lumina_ocr_deskew_warp": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     }
@@ -95,7 +97,7 @@ EXPORTED_SYMBOLS = [
     "lumina_ocr_det_forward", "lumina_ocr_det_postprocess", "lumina_ocr_rec_crop", "lumina_ocr_rec_forward",
     "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing", "lumina_ocr_conv_timing_detail",
     "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients",
-    "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward", "lumina_ocr_svtr_num_classes", "lumina_ocr_svtr_dtype", "lumina_ocr_binarize", "lumina_ocr_deskew", "lumina_ocr_deskew_warp",
+    "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward", "lumina_ocr_svtr_num_classes", "lumina_ocr_svtr_dtype", "lumina_ocr_binarize", "lumina_ocr_grayscale", "lumina_ocr_denoise", "lumina_ocr_deskew", "lumina_ocr_deskew_warp",
 ]
 
 
@@ -363,6 +365,24 @@ class Engine:
         assert c == 3 and img.dtype == torch.uint8
         out = torch.empty_like(img)
         self._chk(self.lib.lumina_ocr_binarize(self._h, _ptr(img), n, h, w, int(bool(adaptive)), int(threshold), _ptr(out), self._stream()))
+        return out
+
+    def grayscale(self, img):
+        """convert_to_grayscale (image_preprocessing.py:167-169): PIL convert('L'), on all three channels.  uint8 [n,H,W,3] device."""
+        torch = _torch()
+        n, h, w, c = img.shape
+        assert c == 3 and img.dtype == torch.uint8
+        out = torch.empty_like(img)
+        self._chk(self.lib.lumina_ocr_grayscale(self._h, _ptr(img), n, h, w, _ptr(out), self._stream()))
+        return out
+
+    def denoise(self, img):
+        """denoise (image_preprocessing.py:160-165): PIL MedianFilter(3) per channel.  uint8 [n,H,W,3] device."""
+        torch = _torch()
+        n, h, w, c = img.shape
+        assert c == 3 and img.dtype == torch.uint8
+        out = torch.empty_like(img)
+        self._chk(self.lib.lumina_ocr_denoise(self._h, _ptr(img), n, h, w, _ptr(out), self._stream()))
         return out
 
     def enhance(self, img, contrast: float = 1.2, sharpness: float = 1.1):

@@ -244,11 +244,12 @@ class OCRService:
     def _finish_page(self, det, jpeg: bytes, processed_hw, page_number: int, original_size, t0: float) -> OCROutput:
         merged, ordered = layout.reading_order(det.triples())
         md = layout.page_markdown(merged)
-        boxes = layout.build_layout_boxes(ordered, page_number)
+        paragraphs = layout.build_paragraph_boxes(merged, page_number)
+        boxes = layout.build_layout_boxes(ordered, page_number) + paragraphs     # words, lines, ..., paragraphs: the order of ocr_service.py:285-367
         ph, pw = processed_hw
         return OCROutput(markdown=md, html=layout.html_from_markdown(md),
                          json_output={"page_count": 1, "words_count": sum(1 for b in boxes if b["type"] == "word"),
-                                      "lines_count": len(ordered), "tables_count": 0, "paragraphs_count": 0},
+                                      "lines_count": len(ordered), "tables_count": 0, "paragraphs_count": len(paragraphs)},
                          processing_time_ms=_ms_since(t0), success=True, page_number=page_number, image_width=original_size[0],
                          image_height=original_size[1], layout_boxes=boxes, processed_image_bytes=jpeg,
                          page_width_inches=float(pw), page_height_inches=float(ph))

@@ -49,6 +49,42 @@ def build_layout_boxes(lines: Sequence[Tuple[Sequence[int], str, float]], page_n
     return words + line_boxes
 
 
+def build_paragraph_boxes(merged: Sequence[MergedLine], page_number: int = 1, gap_ratio: float = 0.7) -> List[Dict[str, Any]]:
+    """`paragraph` entries of the reference schema (/root/reference/backend/services/ocr_service.py:355-367: content cut to 100
+    characters + "...", role, polygon, page_number).  Azure's layout model supplies them there; a det+rec engine derives them from
+    the reading-order lines: consecutive lines belong to one paragraph while the vertical gap between them (top of the next minus
+    bottom of the previous) stays within gap_ratio x their mean height.  Polygon = the axis-aligned hull of the paragraph's line
+    quads (TL, TR, BR, BL); role = "title" for a first paragraph whose lines are at least 1.3 x the page's median line height, else
+    "text" (the reference's fallback for a paragraph without a role, :362)."""
+    rows = []
+    for m in merged:
+        pts = [pt for b in m.blocks for pt in b.box]
+        if not pts or not m.text:
+            continue
+        xs, ys = [p[0] for p in pts], [p[1] for p in pts]
+        rows.append((m.text, min(xs), min(ys), max(xs), max(ys)))
+    if not rows:
+        return []
+    heights = sorted(r[4] - r[2] for r in rows)
+    median_h = heights[len(heights) // 2]
+    groups: List[List[Tuple[str, float, float, float, float]]] = [[rows[0]]]
+    for prev, cur in zip(rows, rows[1:]):
+        mean_h = ((prev[4] - prev[2]) + (cur[4] - cur[2])) / 2.0
+        if cur[2] - prev[4] <= gap_ratio * mean_h:
+            groups[-1].append(cur)
+        else:
+            groups.append([cur])
+    out: List[Dict[str, Any]] = []
+    for gi, g in enumerate(groups):
+        text = " ".join(r[0] for r in g)
+        x0, y0, x1, y1 = min(r[1] for r in g), min(r[2] for r in g), max(r[3] for r in g), max(r[4] for r in g)
+        g_h = sum(r[4] - r[2] for r in g) / len(g)
+        out.append({"type": "paragraph", "content": text[:100] + "..." if len(text) > 100 else text,
+                    "role": "title" if gi == 0 and len(groups) > 1 and g_h >= 1.3 * median_h else "text",
+                    "polygon": [float(x0), float(y0), float(x1), float(y0), float(x1), float(y1), float(x0), float(y1)], "page_number": page_number})
+    return out
+
+
 def reading_order(dets: Sequence[Tuple[Sequence[int], str, float]]) -> Tuple[List[MergedLine], List[Tuple[Sequence[int], str, float]]]:
     """Order detections with the reference's reading-order rules; returns (merged lines, detections in reading order)."""
     blocks = [TextBlock(text=t, confidence=float(s), box=[[float(q[0]), float(q[1])], [float(q[2]), float(q[3])],
@@ -99,4 +135,6 @@ def validate_layout_boxes(boxes: Sequence[Dict[str, Any]]) -> List[str]:
             problems.append(f"{i}: content must be str")
         if b.get("type") == "word" and not isinstance(b.get("confidence"), float):
             problems.append(f"{i}: word confidence must be float")
+        if b.get("type") == "paragraph" and not (isinstance(b.get("content"), str) and len(b["content"]) <= 103 and isinstance(b.get("role"), str)):
+            problems.append(f"{i}: paragraph needs content (<= 100 characters + '...') and role")
     return problems

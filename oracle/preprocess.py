@@ -207,3 +207,24 @@ def adaptive_binarize(img: np.ndarray) -> np.ndarray:
         acc = (acc + (f2[k:k + h, :] * GAUSS11[k]).astype(np.float32)).astype(np.float32)
     mean = np.clip(np.rint(acc), 0, 255).astype(np.int32)
     return np.where(L.astype(np.int32) - mean > -2, 255, 0).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------------------
+# optimize_for_ocr's optional steps (reference: backend/utils/image_preprocessing.py:160-169, :225-231; off by default).
+# PINNED by tests/golden/preprocess_vectors.npz (gray*, denoise*, optimize_dn*, optimize_dn_gray*: produced by the reference module).
+# --------------------------------------------------------------------------------------
+def grayscale(img: np.ndarray) -> np.ndarray:
+    """`convert_to_grayscale` (:167-169) = PIL convert('L') of an RGB image: (19595 R + 38470 G + 7471 B + 0x8000) >> 16.  [H,W,3] -> [H,W]."""
+    if img.ndim == 2:
+        return img.copy()
+    r = img.astype(np.uint32)
+    return ((r[..., 0] * 19595 + r[..., 1] * 38470 + r[..., 2] * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def denoise(img: np.ndarray) -> np.ndarray:
+    """`denoise` (:160-165) = PIL ImageFilter.MedianFilter(3): per channel the median of the 3x3 neighbourhood of the edge-replicated image."""
+    x = img if img.ndim == 3 else img[..., None]
+    p = np.pad(x, ((1, 1), (1, 1), (0, 0)), mode="edge")
+    st = np.stack([p[i:i + x.shape[0], j:j + x.shape[1]] for i in range(3) for j in range(3)])
+    out = np.sort(st, axis=0)[4]
+    return out if img.ndim == 3 else out[..., 0]

@@ -33,6 +33,21 @@ def test_pixel_vectors(i):
     assert np.array_equal(P.optimize_for_ocr(x, 120), v[f"optimize{i}"])
 
 
+@pytest.mark.parametrize("i", range(7))
+def test_optional_steps_grayscale_and_denoise(i):
+    """optimize_for_ocr's optional steps (image_preprocessing.py:160-169, :225-231): oracle restatement vs the reference's own output,
+    alone and inside the whole chain (resize -> [grayscale] -> [denoise] -> contrast -> sharpness)."""
+    v = np.load(G / "preprocess_vectors.npz")
+    x = v[f"in{i}"]
+    assert np.array_equal(P.grayscale(x), v[f"gray{i}"])
+    assert np.array_equal(P.denoise(x), v[f"denoise{i}"])
+    r = P.resize_if_needed(x, 120)
+    dn = P.enhance_sharpness(P.enhance_contrast(P.denoise(r), 1.2), 1.1)
+    assert np.array_equal(dn, v[f"optimize_dn{i}"])
+    dg = P.enhance_sharpness(P.enhance_contrast(P.denoise(P.grayscale(r)), 1.2), 1.1)
+    assert np.array_equal(dg, v[f"optimize_dn_gray{i}"]) and dg.ndim == 2
+
+
 def test_a4_200dpi_page_hashes():
     """BASELINE's page shape: 1654x2339 -> 1414x2000 (int truncation), pinned by SHA-256 of the reference's output."""
     a4 = json.loads((G / "a4_page.json").read_text())

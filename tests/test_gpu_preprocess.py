@@ -96,6 +96,34 @@ def test_resize_alignment_cases_vs_oracle(engine, case):
     assert np.array_equal(got2, got)
 
 
+def test_grayscale_and_denoise_are_byte_exact_with_the_reference(engine):
+    """convert_to_grayscale / denoise (image_preprocessing.py:160-169) and optimize_for_ocr(apply_denoise=True, grayscale=True) (:191-242)
+    on the device vs the reference module's own outputs (tests/golden/preprocess_vectors.npz: gray*, denoise*, optimize_dn*, optimize_dn_gray*)."""
+    from lumina_ocr.utils.image_preprocessing import ImagePreprocessor
+    g = np.load(Path(__file__).parent / "golden" / "preprocess_vectors.npz")
+    pre = ImagePreprocessor(max_dimension=120, engine=engine)
+    for i in range(7):
+        x = g["in%d" % i]
+        rgb = x if x.ndim == 3 else np.repeat(x[..., None], 3, axis=2)          # (an L input: the provider's page format is three-channel)
+        d = torch.from_numpy(np.ascontiguousarray(rgb))[None].cuda()
+        gray = engine.grayscale(d)[0].cpu().numpy()
+        assert np.array_equal(gray[..., 0], g["gray%d" % i]) and np.array_equal(gray[..., 0], gray[..., 1]) and np.array_equal(gray[..., 0], gray[..., 2])
+        dn = engine.denoise(d)[0].cpu().numpy()
+        want = g["denoise%d" % i]
+        assert np.array_equal(dn if want.ndim == 3 else dn[..., 0], want), i
+        if x.ndim == 3:
+            assert np.array_equal(pre.optimize_for_ocr(d, apply_denoise=True)[0].cpu().numpy(), g["optimize_dn%d" % i]), i
+        full = pre.optimize_for_ocr(d, apply_denoise=True, grayscale=True)[0].cpu().numpy()
+        assert np.array_equal(full[..., 0], g["optimize_dn_gray%d" % i]) and np.array_equal(full[..., 0], full[..., 2]), i
+    # a batch of odd-sized pages: every page on its own
+    rng = np.random.default_rng(3)
+    pages = rng.integers(0, 256, (3, 37, 131, 3), dtype=np.uint8)
+    from oracle import preprocess as op
+    out = engine.denoise(torch.from_numpy(pages).cuda()).cpu().numpy()
+    for k in range(3):
+        assert np.array_equal(out[k], op.denoise(pages[k]))
+
+
 def test_binarize_simple_is_the_reference_and_adaptive_matches_its_restatement(engine):
     """image_preprocessing.py:175-185 / :462-494.  simple (L > 128) == the reference's own output in this container (its
     adaptive_binarize falls back to it without OpenCV): pinned by tests/golden (binarize*, adaptive_nocv*).  adaptive == the

@@ -111,7 +111,7 @@ def test_run_ocr_task_contract_fields(service, tmp_path):
     assert d == {"page_number": 1, "width_inches": 640.0, "height_inches": 480.0, "image_width_px": 640, "image_height_px": 480}
     assert isinstance(d["width_inches"], float) and isinstance(d["image_width_px"], int)
     assert layout.validate_layout_boxes(out["layout_boxes"]) == []
-    assert {b["type"] for b in out["layout_boxes"]} == {"line", "word"}   # lines for the matcher, words for its union fallback
+    assert {b["type"] for b in out["layout_boxes"]} == {"line", "word", "paragraph"}   # lines for the matcher, words for its union fallback, paragraphs as in ocr_service.py:355-367
     assert fake.seen_deskew is True                                        # settings.OCR_APPLY_DESKEW default (config.py:85)
     json.dumps(result.to_dict())                                           # stored as JSONB: must serialise, bytes excluded
     assert "processed_image_bytes" not in result.to_dict()["pages"][0]

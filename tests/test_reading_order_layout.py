@@ -119,3 +119,24 @@ def test_provider_without_gpu_fails_loudly_as_data(tmp_path):
         s._allow_synthetic = False
     assert r.success is False and r.pages[0].success is False and "ROCm" in r.error   # no CPU fallback exists
     assert r.pages[0].image_width == 64 and r.pages[0].image_height == 48
+
+
+def test_paragraph_boxes_follow_the_reference_schema():
+    """`paragraph` entries (/root/reference/backend/services/ocr_service.py:355-367): lines grouped by vertical gaps, content cut to
+    100 characters + "...", role "text" unless a taller first paragraph (title), polygon = hull of the lines, accepted by the validator."""
+    from lumina_ocr.utils import layout
+    def q(x0, y0, x1, y1):
+        return [x0, y0, x1, y0, x1, y1, x0, y1]
+    dets = [(q(100, 40, 900, 100), "A BIG TITLE", 0.9),                                    # 60 px tall
+            (q(100, 200, 800, 230), "first line of the body " * 4, 0.9), (q(100, 236, 700, 266), "second line", 0.8),
+            (q(100, 272, 760, 302), "third line", 0.8),                                    # 6 px gaps: one paragraph
+            (q(100, 400, 500, 430), "a separate paragraph", 0.7)]                          # 98 px gap: a new one
+    merged, ordered = layout.reading_order(dets)
+    paras = layout.build_paragraph_boxes(merged, page_number=2)
+    assert [p["role"] for p in paras] == ["title", "text", "text"]
+    assert paras[0]["content"] == "A BIG TITLE" and paras[0]["polygon"] == [100.0, 40.0, 900.0, 40.0, 900.0, 100.0, 100.0, 100.0]
+    body = paras[1]
+    assert body["content"].endswith("...") and len(body["content"]) == 103 and body["polygon"] == [100.0, 200.0, 800.0, 200.0, 800.0, 302.0, 100.0, 302.0]
+    assert paras[2]["content"] == "a separate paragraph" and all(p["page_number"] == 2 and p["type"] == "paragraph" for p in paras)
+    assert layout.validate_layout_boxes(layout.build_layout_boxes(ordered, 2) + paras) == []
+    assert layout.build_paragraph_boxes([], 1) == []

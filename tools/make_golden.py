@@ -76,6 +76,11 @@ def main():
         # binarize (:175-185) and what adaptive_binarize (:462-494) computes in this container (no OpenCV: it falls back to binarize)
         cases[f"binarize{i}"] = np.asarray(small.binarize(im).convert("L"))
         cases[f"adaptive_nocv{i}"] = np.asarray(small.adaptive_binarize(im).convert("L"))
+        # optimize_for_ocr's optional steps (:160-169, :225-231; both default off): 3x3 median, grayscale, and the whole chain with both on
+        cases[f"denoise{i}"] = np.asarray(small.denoise(im))
+        cases[f"gray{i}"] = np.asarray(small.convert_to_grayscale(im))
+        cases[f"optimize_dn_gray{i}"] = np.asarray(small.optimize_for_ocr(im, apply_denoise=True, grayscale=True))
+        cases[f"optimize_dn{i}"] = np.asarray(small.optimize_for_ocr(im, apply_denoise=True))
     np.savez_compressed(OUT / "preprocess_vectors.npz", **cases)
 
     # ---- 3. full-size A4 @ 200 DPI page: hash + a crop (pins the 1654x2339 -> 1414x2000 case BASELINE names) ----
