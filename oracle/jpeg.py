@@ -41,3 +41,46 @@ def compress_for_azure(rgb: np.ndarray, target_size_mb: float = 2.0, initial_qua
             return b
         q -= 10
     raise ValueError("image does not fit the target size without the resize fallback")
+
+
+# ---- decoder (oracle/csrc/jpegdec_oracle.c) ------------------------------------------------------------------------------
+def info(data: bytes):
+    """-> (rc, dict(width, height, ncomp, h, v, restart)); rc 0 = the subset the decoders handle, -2 = valid but unsupported, -1 = corrupt."""
+    L = _lib()
+    a = np.frombuffer(data, np.uint8)
+    out = (ctypes.c_int * 6)()
+    rc = L.oracle_jpeg_info(a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(data)), out)
+    return rc, dict(width=out[0], height=out[1], ncomp=out[2], h=out[3], v=out[4], restart=out[5])
+
+
+def decode(data: bytes) -> np.ndarray:
+    """JPEG file bytes -> uint8 [H,W,3] as Pillow decodes it (a grey-scale file: the grey value on all three channels)."""
+    rc, i = info(data)
+    if rc:
+        raise ValueError("jpeg oracle: %s" % ("unsupported file" if rc == -2 else "corrupt file"))
+    L = _lib()
+    a = np.frombuffer(data, np.uint8)
+    out = np.empty((i["height"], i["width"], 3), np.uint8)
+    nc = ctypes.c_int(0)
+    rc = L.oracle_jpeg_decode_rgb(a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(data)), out.ctypes.data_as(ctypes.c_void_p), i["width"], i["height"], ctypes.byref(nc))
+    if rc:
+        raise ValueError("jpeg oracle: decode failed (%d)" % rc)
+    return out
+
+
+def decode_coefficients(data: bytes) -> np.ndarray:
+    """Quantised coefficients of every block in scan order (natural order inside a block, absolute DC): int16 [blocks, 64]."""
+    rc, i = info(data)
+    if rc:
+        raise ValueError("jpeg oracle: unsupported / corrupt file")
+    mcux = -(-i["width"] // (8 * i["h"])); mcuy = -(-i["height"] // (8 * i["v"]))
+    bpm = i["h"] * i["v"] + (2 if i["ncomp"] == 3 else 0)
+    n = mcux * mcuy * bpm
+    out = np.empty((n, 64), np.int16)
+    L = _lib()
+    L.oracle_jpeg_decode_coefficients.restype = ctypes.c_long
+    a = np.frombuffer(data, np.uint8)
+    got = L.oracle_jpeg_decode_coefficients(a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(data)), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(n))
+    if got != n:
+        raise ValueError("jpeg oracle: coefficient decode failed (%d)" % got)
+    return out

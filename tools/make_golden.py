@@ -172,5 +172,20 @@ def main():
         print("  %-28s %8d bytes" % (p.name, p.stat().st_size))
 
 
+def jpegdec_digests():
+    """tests/golden/jpegdec_digests.json: SHA-256 of every decoder test file (written by Pillow from seeded images, tests/jpeg_cases.py)
+    and of Pillow's decode of it — the decoder behind the reference's load_image (image_preprocessing.py:57-75)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import jpeg_cases as jc
+    out = {}
+    for case in jc.CASES:
+        data = jc.make_file(case)
+        rgb = jc.pil_decode(data)
+        out[case[0]] = dict(file_sha256=hashlib.sha256(data).hexdigest(), rgb_sha256=hashlib.sha256(rgb.tobytes()).hexdigest(),
+                            width=int(rgb.shape[1]), height=int(rgb.shape[0]), file_bytes=len(data))
+    (OUT / "jpegdec_digests.json").write_text(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
     main()
+    jpegdec_digests()
