@@ -149,6 +149,18 @@ int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int
                            uint8_t* out_dev, size_t out_stride, int32_t* sizes_dev, void* stream);
 /* Parity hook for the encoder's first half: quantised DCT coefficients, int16 [n][ceil(w/16)*ceil(h/16)][6][64] in zig-zag order
  * (4 luma, Cb, Cr blocks per MCU; dummy edge blocks resolved). */
+/* JPEG decode on the device — the pixel work of the reference's Image.open(path) / Image.open(BytesIO(bytes)) for .jpg inputs
+ * (ImagePreprocessor.load_image / load_image_bytes, image_preprocessing.py:57-75), byte-identical to Pillow's decode.
+ * lumina_ocr_jpeg_probe (host only, no handle): info = {width, height, components, luma h, luma v, restart interval}; returns 0 for a
+ * file the device decodes (sequential Huffman baseline, 8 bit, grey or YCbCr in one interleaved scan, 4:4:4 / 4:2:2 / 4:2:0),
+ * -1 corrupt / not a JPEG, -2 valid but outside that subset (progressive, CMYK, ...): decode those with Pillow, as the reference does.
+ * lumina_ocr_jpeg_decode: files / sizes are HOST arrays of n file images, all height x width; out_dev uint8 [n][height][width][3]
+ * (a grey file: its value on all three channels); status HOST int [n] (0 ok, -1, -2, -4 = other size: that page is not written).
+ * Synchronises `stream` (the parallel Huffman decode iterates to a fixed point). */
+int lumina_ocr_jpeg_probe(const uint8_t* file, size_t size, int info[6]);
+int lumina_ocr_jpeg_decode(lumina_ocr_t* h, const uint8_t* const* files, const size_t* sizes, int n, int height, int width, uint8_t* out_dev,
+                           int* status, void* stream);
+
 int lumina_ocr_jpeg_coefficients(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, int16_t* coefs_dev,
                                  void* stream);
 

@@ -10,6 +10,7 @@
 #include "ops.h"
 #include "resize.h"
 #include "jpeg.h"
+#include "jpegdec.h"
 #include "stem_conv.h"
 
 #define API_TRY try {
@@ -71,6 +72,7 @@ void lumina_ocr_destroy(lumina_ocr_t* h) {
     for (void* p : h->owned) (void)hipFree(p);
     if (h->ws) (void)hipFree(h->ws);
     if (h->aux) (void)hipFree(h->aux);
+    if (h->jd_stage) (void)hipHostFree(h->jd_stage);
     for (auto& ev : h->conv_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete h;
 }
@@ -318,6 +320,7 @@ int lumina_ocr_resize_lanczos(lumina_ocr_t* h, const uint8_t* in_dev, int n, int
             if (need > h->aux_cap) {
                 if (hipDeviceSynchronize() != hipSuccess) return locr_fail(h, "resize_lanczos", "sync");
                 if (h->aux) (void)hipFree(h->aux);
+    if (h->jd_stage) (void)hipHostFree(h->jd_stage);
                 h->aux = nullptr; h->aux_cap = 0;
                 if (hipMalloc(reinterpret_cast<void**>(&h->aux), need) != hipSuccess) return locr_fail(h, "resize_lanczos", "hipMalloc");
                 h->aux_cap = need;
@@ -384,6 +387,23 @@ int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int
     p.rgb = pages_dev; p.n = n; p.height = height; p.width = width; p.quality = quality; p.optimize = optimize != 0; p.out = out_dev; p.out_stride = out_stride; p.sizes = sizes_dev;
     hipError_t e = jpeg_encode_launch(p, h->ws, (hipStream_t)stream);
     return e == hipSuccess ? 0 : locr_fail(h, "jpeg_encode", hipGetErrorString(e));
+    API_CATCH(h)
+}
+
+int lumina_ocr_jpeg_probe(const uint8_t* file, size_t size, int info[6]) {
+    if (!file || !info) return -1;
+    JdInfo i{};
+    const int rc = jpegdec_probe(file, size, &i);
+    info[0] = i.width; info[1] = i.height; info[2] = i.ncomp; info[3] = i.hs; info[4] = i.vs; info[5] = i.restart;
+    return rc;
+}
+
+int lumina_ocr_jpeg_decode(lumina_ocr_t* h, const uint8_t* const* files, const size_t* sizes, int n, int height, int width, uint8_t* out_dev, int* status,
+                           void* stream) {
+    if (!h || !files || !sizes || !out_dev || !status || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "jpeg_decode", "bad arguments");
+    BIND(h);
+    API_TRY
+    return jpegdec_run(h, files, sizes, n, height, width, out_dev, status, (hipStream_t)stream);
     API_CATCH(h)
 }
 

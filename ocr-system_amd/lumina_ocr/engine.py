@@ -66,6 +66,8 @@ def load_library() -> ctypes.CDLL:
         "lumina_ocr_resize_lanczos": (i32, [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
         "lumina_ocr_enhance": (i32, [vp, vp, i32, i32, i32, f32, f32, vp, vp, vp]),
         "lumina_ocr_jpeg_encode": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
+        "lumina_ocr_jpeg_probe": (i32, [vp, sz, vp]),
+        "lumina_ocr_jpeg_decode": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
         "lumina_ocr_jpeg_coefficients": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
         "lumina_ocr_load_svtr_weights": (i32, [vp, vp, sz]),
         "lumina_ocr_svtr_forward": (i32, [vp, vp, vp, i32, vp, vp, vp]),
@@ -96,7 +98,7 @@ EXPORTED_SYMBOLS = [
     "lumina_ocr_load_det_weights", "lumina_ocr_load_rec_weights", "lumina_ocr_num_classes", "lumina_ocr_normalize",
     "lumina_ocr_det_forward", "lumina_ocr_det_postprocess", "lumina_ocr_rec_crop", "lumina_ocr_rec_forward",
     "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing", "lumina_ocr_conv_timing_detail",
-    "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients",
+    "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients", "lumina_ocr_jpeg_probe", "lumina_ocr_jpeg_decode",
     "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward", "lumina_ocr_svtr_num_classes", "lumina_ocr_svtr_dtype", "lumina_ocr_binarize", "lumina_ocr_grayscale", "lumina_ocr_denoise", "lumina_ocr_deskew", "lumina_ocr_deskew_warp",
 ]
 
@@ -160,6 +162,30 @@ class Engine:
         self._chk(self.lib.lumina_ocr_jpeg_encode(self._h, _ptr(pages), n, h, w, int(quality), int(bool(optimize)), _ptr(out), stride, _ptr(sizes),
                                                   self._stream()))
         return out, sizes
+
+    @staticmethod
+    def jpeg_probe(data: bytes):
+        """Host only. -> (rc, dict(width, height, ncomp, h, v, restart)); rc 0: the device decodes this file, -2: valid JPEG outside the
+        subset (progressive, CMYK ...: decode with Pillow as the reference does), -1: corrupt / not a JPEG."""
+        lib = load_library()
+        info = (ctypes.c_int * 6)()
+        buf = ctypes.c_char_p(data)
+        rc = lib.lumina_ocr_jpeg_probe(buf, len(data), info)
+        return rc, dict(width=info[0], height=info[1], ncomp=info[2], h=info[3], v=info[4], restart=info[5])
+
+    def jpeg_decode(self, files, height: int, width: int, out=None):
+        """JPEG file images (a sequence of bytes objects, all height x width) -> (uint8 [n,H,W,3] device, status list): the pixel work of
+        the reference's Image.open for .jpg inputs (image_preprocessing.py:57-75), byte-identical to Pillow's decode.  status[i] != 0:
+        page i was not decoded (-1 corrupt, -2 outside the device subset, -4 another size): the caller falls back to Pillow for it."""
+        torch = _torch()
+        n = len(files)
+        if out is None:
+            out = torch.empty((n, height, width, 3), dtype=torch.uint8, device=torch.device("cuda", self.device))
+        ptrs = (ctypes.c_char_p * n)(*files)
+        sizes = (ctypes.c_size_t * n)(*[len(f) for f in files])
+        status = (ctypes.c_int * n)()
+        self._chk(self.lib.lumina_ocr_jpeg_decode(self._h, ptrs, sizes, n, int(height), int(width), _ptr(out), status, self._stream()))
+        return out, list(status)
 
     def jpeg_coefficients(self, pages, quality: int = 95):
         torch = _torch()
