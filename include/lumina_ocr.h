@@ -160,6 +160,8 @@ int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int
 int lumina_ocr_jpeg_probe(const uint8_t* file, size_t size, int info[6]);
 int lumina_ocr_jpeg_decode(lumina_ocr_t* h, const uint8_t* const* files, const size_t* sizes, int n, int height, int width, uint8_t* out_dev,
                            int* status, void* stream);
+/* synchronisation passes over the chunk decoders the last lumina_ocr_jpeg_decode call needed (diagnostic) */
+int lumina_ocr_jpeg_last_passes(const lumina_ocr_t* h);
 
 int lumina_ocr_jpeg_coefficients(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, int16_t* coefs_dev,
                                  void* stream);

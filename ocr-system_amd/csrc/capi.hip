@@ -407,6 +407,8 @@ int lumina_ocr_jpeg_decode(lumina_ocr_t* h, const uint8_t* const* files, const s
     API_CATCH(h)
 }
 
+int lumina_ocr_jpeg_last_passes(const lumina_ocr_t* h) { return h ? h->jd_last_passes : 0; }
+
 int lumina_ocr_jpeg_coefficients(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int height, int width, int quality, int16_t* coefs_dev,
                                  void* stream) {
     if (!h || !pages_dev || !coefs_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "jpeg_coefficients", "bad arguments");

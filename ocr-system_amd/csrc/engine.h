@@ -123,6 +123,7 @@ struct lumina_ocr {
     std::map<std::pair<int, int>, Coeffs> coeff_cache;  // (in, out) -> device tables
     uint8_t* aux = nullptr; size_t aux_cap = 0;         // resize intermediate
     unsigned long long* sums = nullptr; int sums_cap = 0;
+    int jd_last_passes = 0;   // synchronisation passes the last JPEG decode needed (incl. the one that found nothing to change)
     uint8_t* jd_stage = nullptr; size_t jd_stage_cap = 0;   // pinned staging buffer of the JPEG decoder (jpegdec.hip)
     float* dk_trig = nullptr; short* dk_wtab = nullptr;   // de-skew tables (deskew.h), uploaded at first use
 };

@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int JD_CH = 256;      // clean-stream bytes per chunk
+constexpr int JD_CH = 1024;     // clean-stream bytes per chunk (256: a busy A4 page holds ~3 MCUs per chunk and only 36 % of the guessed starts re-synchronise inside it: 28 passes; 1024: 8)
 constexpr int JD_UB = 1024;     // raw bytes per un-stuff block (256 threads x 4)
 constexpr int JD_PASSES = 4;    // synchronisation passes between two looks at the "changed" flags
 
@@ -545,8 +545,12 @@ int parse_header(const uint8_t* f, size_t n, HostHeader* h) {
     if (e < h->scan_off + 2) return -1;
     h->scan_end = e - 2;
     // any marker other than RSTn inside the scan (DNL, a second SOS ...) is outside the subset
-    for (size_t i = h->scan_off; i + 1 < h->scan_end; ++i)
-        if (f[i] == 0xFF && f[i + 1] != 0x00 && !((f[i + 1] & 0xF8) == 0xD0) && f[i + 1] != 0xFF) return -2;
+    for (const uint8_t* q = f + h->scan_off; q + 1 < f + h->scan_end;) {   // (memchr: the scan is megabytes, 0xFF bytes are rare)
+        q = static_cast<const uint8_t*>(memchr(q, 0xFF, (size_t)(f + h->scan_end - 1 - q)));
+        if (q == nullptr) break;
+        if (q[1] != 0x00 && (q[1] & 0xF8) != 0xD0 && q[1] != 0xFF) return -2;
+        ++q;
+    }
     return 0;
 }
 
@@ -595,6 +599,7 @@ int jpegdec_probe(const uint8_t* file, size_t n, JdInfo* info) {
 
 int jpegdec_run(lumina_ocr* eng, const uint8_t* const* files, const size_t* sizes, int n, int height, int width, uint8_t* out_dev, int* status, hipStream_t st) {
     std::vector<JdFile> F((size_t)n);
+    std::vector<const uint8_t*> scan_src((size_t)n, nullptr);
     // the scan bytes of all files go through ONE pinned staging buffer (kept by the engine) and ONE asynchronous copy
     size_t raw_cap = 0;
     for (int i = 0; i < n; ++i) raw_cap += ((sizes[i] + 16 + 255) & ~(size_t)255);
@@ -635,8 +640,7 @@ int jpegdec_run(lumina_ocr* eng, const uint8_t* const* files, const size_t* size
         f.raw_len = (unsigned)(h.scan_end - h.scan_off);
         f.raw_off = (unsigned)raw_total; f.clean_off = f.raw_off;
         const size_t padded = ((size_t)f.raw_len + 16 + 255) & ~(size_t)255;   // (the bit reader loads three aligned words past its position)
-        memcpy(raw + raw_total, files[i] + h.scan_off, f.raw_len);
-        memset(raw + raw_total + f.raw_len, 0, padded - f.raw_len);
+        scan_src[(size_t)i] = files[i] + h.scan_off;
         raw_total += padded;
         f.nublk = (f.raw_len + JD_UB - 1) / JD_UB; f.ublk_off = (unsigned)ublk_total; ublk_total += f.nublk;
         f.nchunk_cap = (f.raw_len + JD_CH - 1) / JD_CH + 1; f.chunk_off = (unsigned)chunk_total; chunk_total += f.nchunk_cap;
@@ -673,7 +677,23 @@ int jpegdec_run(lumina_ocr* eng, const uint8_t* const* files, const size_t* size
     int* dChanged = carve<int>(p, (size_t)n * (JD_PASSES + 1));
     if ((size_t)(p - eng->ws) > eng->ws_cap) return locr_fail(eng, "jpeg_decode", "workspace layout exceeds the reservation");
     JDCHK(hipMemcpyAsync(dF, F.data(), sizeof(JdFile) * n, hipMemcpyHostToDevice, st));
-    JDCHK(hipMemcpyAsync(dRaw, raw, raw_total, hipMemcpyHostToDevice, st));
+    // scan bytes: host copy into the pinned buffer and the asynchronous upload of the previous files overlap (groups of ~8 MB)
+    {
+        size_t sent = 0;
+        for (int i = 0; i < n; ++i) {
+            const JdFile& f = F[(size_t)i];
+            if (!f.valid) continue;
+            const size_t padded = ((size_t)f.raw_len + 16 + 255) & ~(size_t)255;
+            memcpy(raw + f.raw_off, scan_src[(size_t)i], f.raw_len);
+            memset(raw + f.raw_off + f.raw_len, 0, padded - f.raw_len);
+            const size_t end = (size_t)f.raw_off + padded;
+            if (end - sent >= (8u << 20) || end == raw_total) {
+                JDCHK(hipMemcpyAsync(dRaw + sent, raw + sent, end - sent, hipMemcpyHostToDevice, st));
+                sent = end;
+            }
+        }
+        if (sent < raw_total) JDCHK(hipMemcpyAsync(dRaw + sent, raw + sent, raw_total - sent, hipMemcpyHostToDevice, st));
+    }
     JDCHK(hipMemsetAsync(dClean, 0, raw_total + 64, st));
     JDCHK(hipMemsetAsync(dCoef, 0, blk_total * 128, st));
     // ---- 1. un-stuff ----
@@ -694,6 +714,7 @@ int jpegdec_run(lumina_ocr* eng, const uint8_t* const* files, const size_t* size
         if (!again) break;
         if ((unsigned)pass > max_chunks + JD_PASSES) return locr_fail(eng, "jpeg_decode", "the chunk decoders did not reach a fixed point");
     }
+    eng->jd_last_passes = pass;
     // ---- 3. coefficients, DC, IDCT, colour ----
     hipLaunchKernelGGL(jd_blkscan_kernel, dim3(n), dim3(256), 0, st, dF, dD, C);
     hipLaunchKernelGGL(jd_write_kernel, cgrid, dim3(64), 0, st, dF, dD, dClean, dSeg, C, dCoef);

@@ -67,6 +67,7 @@ def load_library() -> ctypes.CDLL:
         "lumina_ocr_enhance": (i32, [vp, vp, i32, i32, i32, f32, f32, vp, vp, vp]),
         "lumina_ocr_jpeg_encode": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
         "lumina_ocr_jpeg_probe": (i32, [vp, sz, vp]),
+        "lumina_ocr_jpeg_last_passes": (i32, [vp]),
         "lumina_ocr_jpeg_decode": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
         "lumina_ocr_jpeg_coefficients": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
         "lumina_ocr_load_svtr_weights": (i32, [vp, vp, sz]),
@@ -98,7 +99,7 @@ EXPORTED_SYMBOLS = [
     "lumina_ocr_load_det_weights", "lumina_ocr_load_rec_weights", "lumina_ocr_num_classes", "lumina_ocr_normalize",
     "lumina_ocr_det_forward", "lumina_ocr_det_postprocess", "lumina_ocr_rec_crop", "lumina_ocr_rec_forward",
     "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing", "lumina_ocr_conv_timing_detail",
-    "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients", "lumina_ocr_jpeg_probe", "lumina_ocr_jpeg_decode",
+    "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients", "lumina_ocr_jpeg_probe", "lumina_ocr_jpeg_decode", "lumina_ocr_jpeg_last_passes",
     "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward", "lumina_ocr_svtr_num_classes", "lumina_ocr_svtr_dtype", "lumina_ocr_binarize", "lumina_ocr_grayscale", "lumina_ocr_denoise", "lumina_ocr_deskew", "lumina_ocr_deskew_warp",
 ]
 
@@ -186,6 +187,10 @@ class Engine:
         status = (ctypes.c_int * n)()
         self._chk(self.lib.lumina_ocr_jpeg_decode(self._h, ptrs, sizes, n, int(height), int(width), _ptr(out), status, self._stream()))
         return out, list(status)
+
+    @property
+    def jpeg_last_passes(self) -> int:
+        return int(self.lib.lumina_ocr_jpeg_last_passes(self._h))
 
     def jpeg_coefficients(self, pages, quality: int = 95):
         torch = _torch()

@@ -106,6 +106,7 @@ class OCRService:
         # settings.PREPROCESSING_APPLY_BINARIZE (ocr_service.py:151, default False): "true" / "adaptive" = cv2.adaptiveThreshold semantics,
         # "simple" = the L > 128 threshold the reference falls back to without OpenCV (image_preprocessing.py:473-475)
         b = os.environ.get("PREPROCESSING_APPLY_BINARIZE", "false").lower()
+        self.device_jpeg = os.environ.get("LUMINA_OCR_DEVICE_JPEG", "1").lower() not in ("0", "false", "no")   # baseline JPEG inputs are decoded on the device
         self.apply_binarize = "adaptive" if b in ("1", "true", "yes", "adaptive") else ("simple" if b == "simple" else None)
         self._device = int(os.environ.get("LUMINA_OCR_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self._det_weights = os.environ.get("LUMINA_OCR_DET_WEIGHTS", "")
@@ -254,16 +255,24 @@ class OCRService:
                          image_height=original_size[1], layout_boxes=boxes, processed_image_bytes=jpeg,
                          page_width_inches=float(pw), page_height_inches=float(ph))
 
-    def _process_single_image_sync(self, image: Image.Image, page_number: int = 1) -> OCROutput:
+    def _process_single_image_sync(self, image: Image.Image, page_number: int = 1, decoded=None) -> OCROutput:
+        """decoded: the page already on the device (uint8 [1,H,W,3], from the device JPEG decoder) — `image` is then only consulted
+        for its size."""
         with self._semaphore:
             t0 = time.time()
             original_size = image.size
             try:
                 import torch
                 self._ensure_engine()
-                page = self._prepare(image)
                 with self._device_ctx():
-                    dets, processed = self._pipeline.run(self._upload(self._stage_pages([page])), deskew=self.apply_deskew)
+                    if decoded is None:
+                        decoded = self._upload(self._stage_pages([self._prepare(image)]))
+                    else:
+                        w, h = original_size
+                        nw, nh = get_optimal_size(w, h, self.max_dimension)
+                        if nw <= 0 or nh <= 0:
+                            raise ValueError("height and width must be > 0")
+                    dets, processed = self._pipeline.run(decoded, deskew=self.apply_deskew)
                     jpeg = self._pre.compress_for_azure_device(processed)[0]   # processed_image_bytes: encoded on the device
                 return self._finish_page(dets[0], jpeg, tuple(processed.shape[1:3]), page_number, original_size, t0)
             except Exception as e:  # errors are data (:464-475)
@@ -271,16 +280,46 @@ class OCRService:
                 return OCROutput(success=False, error=str(e), processing_time_ms=_ms_since(t0), page_number=page_number,
                                  image_width=original_size[0], image_height=original_size[1])
 
+    def _decode_jpeg_on_device(self, data: bytes, image: Image.Image):
+        """The reference decodes every input with Image.open (image_preprocessing.py:57-75).  For a baseline JPEG without an EXIF rotation
+        the pixels are produced on the device instead (lumina_ocr_jpeg_decode: byte-identical to Pillow's decode; grey files arrive with
+        their value on all three channels, which is what convert('RGB') gives): nothing is decoded on the host, the file's
+        entropy-coded bytes are what crosses PCIe (~10x less than the pixels).  -> device tensor [1,H,W,3], or None: Pillow decodes."""
+        if not self.device_jpeg or image.format != "JPEG" or data[:2] != b"\xff\xd8":
+            return None
+        try:
+            if image.getexif().get(0x0112, 1) not in (0, 1):
+                return None                                   # an orientation to apply: the host path (ImageOps.exif_transpose)
+            from ..engine import Engine
+            rc, info = Engine.jpeg_probe(data)
+            if rc != 0 or (info["width"], info["height"]) != image.size:
+                return None
+            self._ensure_engine()
+            with self._device_ctx():
+                out, status = self._engine.jpeg_decode([data], info["height"], info["width"])
+            return out if status == [0] else None
+        except Exception as e:       # any doubt: the reference's own path
+            logger.warning("device JPEG decode not used: %s", e)
+            return None
+
     def process_image_sync(self, image_source: Union[str, Path, Image.Image, bytes], page_number: int = 1) -> OCROutput:
+        data = None
         if isinstance(image_source, bytes):
+            data = image_source
             image = self._pre.load_image_bytes(image_source)
         elif isinstance(image_source, (str, Path)):
             image = self._pre.load_image(image_source)
+            if getattr(image, "format", None) == "JPEG" and self.device_jpeg:
+                try:
+                    data = Path(image_source).read_bytes()
+                except OSError:
+                    data = None
         elif isinstance(image_source, Image.Image):
             image = image_source
         else:
             raise ValueError(f"Unsupported image type: {type(image_source)}")
-        return self._process_single_image_sync(image, page_number)
+        decoded = self._decode_jpeg_on_device(data, image) if data is not None else None      # (Image.open is lazy: no pixel was decoded yet)
+        return self._process_single_image_sync(image, page_number, decoded=decoded)
 
     # ---- page batches: the data-parallel unit (reference loops pages serially, :620-627) ----
     def process_pages_sync(self, images: List[Image.Image], first_page_number: int = 1) -> List[OCROutput]:

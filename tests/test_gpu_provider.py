@@ -100,3 +100,42 @@ def test_degenerate_page_sizes_are_processed(service, size, mode):
     assert out.processed_image_bytes[:2] == b"\xff\xd8" and out.processed_image_bytes[-2:] == b"\xff\xd9"
     im = Image.open(io.BytesIO(out.processed_image_bytes))
     assert im.size == (int(out.page_width_inches), int(out.page_height_inches))
+
+
+def test_jpeg_inputs_are_decoded_on_the_device_with_the_same_result(service, tmp_path):
+    """A .jpg input (path, bytes, through process_document): the provider decodes baseline JPEGs on the device (lumina_ocr_jpeg_decode,
+    byte-identical to the Image.open of the reference, image_preprocessing.py:57-75) — same boxes, same markdown, same processed JPEG as the
+    host-decoded path; a progressive file, an EXIF-rotated file and a PNG still take the reference's own path."""
+    s = service
+    page = synth.synth_page(700, 1000, 9, n_lines=12)[0]
+    f = tmp_path / "scan.jpg"
+    Image.fromarray(page).save(f, format="JPEG", quality=92)
+    s._ensure_engine()
+    calls = []
+    real = s._engine.jpeg_decode
+    s._engine.jpeg_decode = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    s.device_jpeg = False
+    host = s.process_image_sync(f)
+    assert host.success and not calls
+    s.device_jpeg = True
+    dev_path = s.process_image_sync(f)
+    dev_bytes = s.process_image_sync(f.read_bytes())
+    doc = asyncio.run(s.process_document(f, "jpg"))
+    assert len(calls) == 3
+    for r in (dev_path, dev_bytes, doc.pages[0]):
+        assert r.success and r.layout_boxes == host.layout_boxes and r.markdown == host.markdown
+        assert r.processed_image_bytes == host.processed_image_bytes and (r.image_width, r.image_height) == (1000, 700)
+    # files the device decoder does not take: same results through Pillow, no device decode call
+    prog = tmp_path / "prog.jpg"
+    Image.fromarray(page).save(prog, format="JPEG", quality=92, progressive=True)
+    rot = tmp_path / "rot.jpg"
+    ex = Image.Exif()
+    ex[0x0112] = 6
+    Image.fromarray(page).save(rot, format="JPEG", quality=92, exif=ex)
+    png = tmp_path / "page.png"
+    Image.fromarray(page).save(png)
+    n0 = len(calls)
+    r_prog, r_rot, r_png = s.process_image_sync(prog), s.process_image_sync(rot), s.process_image_sync(png)
+    assert len(calls) == n0 and r_prog.success and r_rot.success and r_png.success
+    assert (r_rot.image_width, r_rot.image_height) == (1000, 700)          # original size as stored (ocr_service.py:406), boxes on the rotated page
+    assert r_rot.page_width_inches == 700.0 and r_rot.page_height_inches == 1000.0
