@@ -160,6 +160,11 @@ int lumina_ocr_jpeg_encode(lumina_ocr_t* h, const uint8_t* pages_dev, int n, int
 int lumina_ocr_jpeg_probe(const uint8_t* file, size_t size, int info[6]);
 int lumina_ocr_jpeg_decode(lumina_ocr_t* h, const uint8_t* const* files, const size_t* sizes, int n, int height, int width, uint8_t* out_dev,
                            int* status, void* stream);
+/* The same without any host synchronisation (a pipeline decodes the next batch while the device still works on the previous one): `passes`
+ * synchronisation passes are enqueued blindly (12 suffice for 1 KB chunks on busy A4 pages: 8 needed), `status_pinned` must be pinned host
+ * memory and is valid once `stream` has run; -5 = the passes did not reach the fixed point (decode that batch again with the form above). */
+int lumina_ocr_jpeg_decode_async(lumina_ocr_t* h, const uint8_t* const* files, const size_t* sizes, int n, int height, int width, uint8_t* out_dev,
+                                 int* status_pinned, int passes, void* stream);
 /* synchronisation passes over the chunk decoders the last lumina_ocr_jpeg_decode call needed (diagnostic) */
 int lumina_ocr_jpeg_last_passes(const lumina_ocr_t* h);
 

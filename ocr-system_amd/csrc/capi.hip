@@ -72,7 +72,7 @@ void lumina_ocr_destroy(lumina_ocr_t* h) {
     for (void* p : h->owned) (void)hipFree(p);
     if (h->ws) (void)hipFree(h->ws);
     if (h->aux) (void)hipFree(h->aux);
-    if (h->jd_stage) (void)hipHostFree(h->jd_stage);
+    for (int k = 0; k < 2; ++k) { if (h->jd_stage[k]) (void)hipHostFree(h->jd_stage[k]); if (h->jd_stage_ev[k]) (void)hipEventDestroy(h->jd_stage_ev[k]); }
     for (auto& ev : h->conv_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete h;
 }
@@ -320,7 +320,7 @@ int lumina_ocr_resize_lanczos(lumina_ocr_t* h, const uint8_t* in_dev, int n, int
             if (need > h->aux_cap) {
                 if (hipDeviceSynchronize() != hipSuccess) return locr_fail(h, "resize_lanczos", "sync");
                 if (h->aux) (void)hipFree(h->aux);
-    if (h->jd_stage) (void)hipHostFree(h->jd_stage);
+    for (int k = 0; k < 2; ++k) { if (h->jd_stage[k]) (void)hipHostFree(h->jd_stage[k]); if (h->jd_stage_ev[k]) (void)hipEventDestroy(h->jd_stage_ev[k]); }
                 h->aux = nullptr; h->aux_cap = 0;
                 if (hipMalloc(reinterpret_cast<void**>(&h->aux), need) != hipSuccess) return locr_fail(h, "resize_lanczos", "hipMalloc");
                 h->aux_cap = need;
@@ -404,6 +404,15 @@ int lumina_ocr_jpeg_decode(lumina_ocr_t* h, const uint8_t* const* files, const s
     BIND(h);
     API_TRY
     return jpegdec_run(h, files, sizes, n, height, width, out_dev, status, (hipStream_t)stream);
+    API_CATCH(h)
+}
+
+int lumina_ocr_jpeg_decode_async(lumina_ocr_t* h, const uint8_t* const* files, const size_t* sizes, int n, int height, int width, uint8_t* out_dev,
+                                 int* status_pinned, int passes, void* stream) {
+    if (!h || !files || !sizes || !out_dev || !status_pinned || n <= 0 || height <= 0 || width <= 0 || passes < 2) return locr_fail(h, "jpeg_decode_async", "bad arguments");
+    BIND(h);
+    API_TRY
+    return jpegdec_run(h, files, sizes, n, height, width, out_dev, status_pinned, (hipStream_t)stream, passes);
     API_CATCH(h)
 }
 

@@ -124,7 +124,7 @@ struct lumina_ocr {
     uint8_t* aux = nullptr; size_t aux_cap = 0;         // resize intermediate
     unsigned long long* sums = nullptr; int sums_cap = 0;
     int jd_last_passes = 0;   // synchronisation passes the last JPEG decode needed (incl. the one that found nothing to change)
-    uint8_t* jd_stage = nullptr; size_t jd_stage_cap = 0;   // pinned staging buffer of the JPEG decoder (jpegdec.hip)
+    uint8_t* jd_stage[2] = {nullptr, nullptr}; size_t jd_stage_cap[2] = {0, 0}; hipEvent_t jd_stage_ev[2] = {nullptr, nullptr}; int jd_stage_next = 0;   // pinned staging buffers of the JPEG decoder (jpegdec.hip)
     float* dk_trig = nullptr; short* dk_wtab = nullptr;   // de-skew tables (deskew.h), uploaded at first use
 };
 

@@ -18,5 +18,7 @@ struct lumina_ocr;
 // [n][height][width][3] (grey-scale files: the grey value on all three channels).  status: HOST int [n], 0 ok / -1 corrupt /
 // -2 unsupported / -4 size mismatch (such a page's pixels are not written).  Synchronises the stream once (the parallel
 // Huffman decode iterates to a fixed point and reads back one flag per pass group).
+// async_passes > 0: nothing is synchronised — that many synchronisation passes are enqueued, `status` must be PINNED host memory and is
+// valid once the stream has run (-5 = the passes did not reach the fixed point: decode that batch again with the synchronous form).
 int jpegdec_run(lumina_ocr* eng, const uint8_t* const* files, const size_t* sizes, int n, int height, int width, uint8_t* out_dev, int* status,
-                hipStream_t st);
+                hipStream_t st, int async_passes = 0);

@@ -453,6 +453,15 @@ __global__ __launch_bounds__(256) void jd_color_kernel(const JdFile* files, cons
     o[2] = jd_clamp(yy + ((116130 * cb + 32768) >> 16));
 }
 
+// per-file outcome of an asynchronous decode: host parse code, else -1 (corrupt), -5 (the fixed number of passes did not reach the fixed point), 0
+__global__ void jd_status_kernel(const JdFile* files, const JdDyn* dyn, const int* host_rc, const int* changed_last, int* status, int n) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    int rc = host_rc[i];
+    if (rc == 0 && files[i].valid) rc = dyn[i].nseg < 0 ? -1 : (changed_last[i] ? -5 : (dyn[i].err ? -1 : 0));   // (before the fixed point the error flag means nothing)
+    status[i] = rc;
+}
+
 // ------------------------------------------------------------------------------------------------ host: headers
 struct HostHeader {
     int width = 0, height = 0, ncomp = 0, hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0}, restart = 0;
@@ -597,19 +606,26 @@ int jpegdec_probe(const uint8_t* file, size_t n, JdInfo* info) {
     return rc;
 }
 
-int jpegdec_run(lumina_ocr* eng, const uint8_t* const* files, const size_t* sizes, int n, int height, int width, uint8_t* out_dev, int* status, hipStream_t st) {
+int jpegdec_run(lumina_ocr* eng, const uint8_t* const* files, const size_t* sizes, int n, int height, int width, uint8_t* out_dev, int* status, hipStream_t st,
+                int async_passes) {
+    // async_passes > 0: that many synchronisation passes are enqueued without looking at their result, nothing is synchronised, and
+    // `status` (PINNED host memory of the caller) is filled by a copy at the end of the stream's work: -5 = the passes did not suffice
     std::vector<JdFile> F((size_t)n);
     std::vector<const uint8_t*> scan_src((size_t)n, nullptr);
     // the scan bytes of all files go through ONE pinned staging buffer (kept by the engine) and ONE asynchronous copy
     size_t raw_cap = 0;
     for (int i = 0; i < n; ++i) raw_cap += ((sizes[i] + 16 + 255) & ~(size_t)255);
-    if (raw_cap > eng->jd_stage_cap) {
-        if (eng->jd_stage) (void)hipHostFree(eng->jd_stage);
-        eng->jd_stage = nullptr; eng->jd_stage_cap = 0;
-        JDCHK(hipHostMalloc(reinterpret_cast<void**>(&eng->jd_stage), raw_cap, hipHostMallocDefault));
-        eng->jd_stage_cap = raw_cap;
+    // two staging buffers in turn: an asynchronous call's upload may still be queued when the next call fills its buffer
+    const int sb = eng->jd_stage_next; eng->jd_stage_next ^= 1;
+    if (eng->jd_stage_ev[sb]) JDCHK(hipEventSynchronize(eng->jd_stage_ev[sb]));
+    else JDCHK(hipEventCreateWithFlags(&eng->jd_stage_ev[sb], hipEventDisableTiming));
+    if (raw_cap > eng->jd_stage_cap[sb]) {
+        if (eng->jd_stage[sb]) (void)hipHostFree(eng->jd_stage[sb]);
+        eng->jd_stage[sb] = nullptr; eng->jd_stage_cap[sb] = 0;
+        JDCHK(hipHostMalloc(reinterpret_cast<void**>(&eng->jd_stage[sb]), raw_cap + 4096, hipHostMallocDefault));
+        eng->jd_stage_cap[sb] = raw_cap;
     }
-    uint8_t* raw = eng->jd_stage;
+    uint8_t* raw = eng->jd_stage[sb];
     size_t raw_total = 0, ublk_total = 0, chunk_total = 0, seg_total = 0, blk_total = 0, plane_total = 0;
     unsigned max_ublk = 0, max_chunks = 0;
     int max_blk = 0, any = 0;
@@ -651,13 +667,13 @@ int jpegdec_run(lumina_ocr* eng, const uint8_t* const* files, const size_t* size
         if (f.nblk > max_blk) max_blk = f.nblk;
         if (raw_total >= (1ull << 31) || blk_total >= (1ull << 31)) return locr_fail(eng, "jpeg_decode", "batch too large (2 GiB of scan data / 2^31 blocks)");
     }
-    if (!any) return 0;
+    if (!any) { if (async_passes > 0) { /* status is already final */ } return 0; }
     // ---- workspace ----
     size_t need = 4096;
     auto add = [&](size_t bytes) { need += (bytes + 255) & ~(size_t)255; };
     add(sizeof(JdFile) * n); add(sizeof(JdDyn) * n); add(raw_total); add(raw_total + 64); add(4 * ublk_total * 2 + 64); add(4 * seg_total);
     for (int k = 0; k < 8; ++k) add(4 * chunk_total + 64);
-    add(blk_total * 128); add(plane_total); add(4 * (size_t)n * (JD_PASSES + 1)); add(4096);
+    add(blk_total * 128); add(plane_total); add(4 * (size_t)n * (JD_PASSES + 1)); add(4096); add(8 * (size_t)n + 512);
     if (eng_ws_reserve(eng, need)) return 1;
     uint8_t* p = eng->ws;
     JdFile* dF = carve<JdFile>(p, (size_t)n);
@@ -675,6 +691,8 @@ int jpegdec_run(lumina_ocr* eng, const uint8_t* const* files, const size_t* size
     short* dCoef = carve<short>(p, blk_total * 64);
     uint8_t* dPlane = carve<uint8_t>(p, plane_total);
     int* dChanged = carve<int>(p, (size_t)n * (JD_PASSES + 1));
+    int* dHostRc = carve<int>(p, (size_t)n);
+    int* dStatus = carve<int>(p, (size_t)n);
     if ((size_t)(p - eng->ws) > eng->ws_cap) return locr_fail(eng, "jpeg_decode", "workspace layout exceeds the reservation");
     JDCHK(hipMemcpyAsync(dF, F.data(), sizeof(JdFile) * n, hipMemcpyHostToDevice, st));
     // scan bytes: host copy into the pinned buffer and the asynchronous upload of the previous files overlap (groups of ~8 MB)
@@ -694,6 +712,7 @@ int jpegdec_run(lumina_ocr* eng, const uint8_t* const* files, const size_t* size
         }
         if (sent < raw_total) JDCHK(hipMemcpyAsync(dRaw + sent, raw + sent, raw_total - sent, hipMemcpyHostToDevice, st));
     }
+    JDCHK(hipEventRecord(eng->jd_stage_ev[sb], st));   // the staging buffer is free again once the uploads have run
     JDCHK(hipMemsetAsync(dClean, 0, raw_total + 64, st));
     JDCHK(hipMemsetAsync(dCoef, 0, blk_total * 128, st));
     // ---- 1. un-stuff ----
@@ -704,6 +723,25 @@ int jpegdec_run(lumina_ocr* eng, const uint8_t* const* files, const size_t* size
     std::vector<int> changed((size_t)n * (JD_PASSES + 1));
     const dim3 cgrid((max_chunks + 63) / 64, n);
     int pass = 0;
+    if (async_passes > 0) {
+        // host parse codes travel with the call (the descriptor upload above was from pageable memory: already consumed)
+        JDCHK(hipMemcpyAsync(dHostRc, status, sizeof(int) * n, hipMemcpyHostToDevice, st));
+        JDCHK(hipMemsetAsync(dChanged, 0, sizeof(int) * (size_t)n * (JD_PASSES + 1), st));
+        for (; pass < async_passes; ++pass) {
+            if (pass == async_passes - 1) JDCHK(hipMemsetAsync(dChanged, 0, sizeof(int) * n, st));
+            hipLaunchKernelGGL(jd_sync_kernel, cgrid, dim3(64), 0, st, dF, dD, dClean, dSeg, C, pass, dChanged);
+        }
+        eng->jd_last_passes = pass;
+        hipLaunchKernelGGL(jd_blkscan_kernel, dim3(n), dim3(256), 0, st, dF, dD, C);
+        hipLaunchKernelGGL(jd_write_kernel, cgrid, dim3(64), 0, st, dF, dD, dClean, dSeg, C, dCoef);
+        hipLaunchKernelGGL(jd_dc_kernel, dim3(3, n), dim3(256), 0, st, dF, dD, dCoef);
+        hipLaunchKernelGGL(jd_idct_kernel, dim3((max_blk + 31) / 32, n), dim3(256), 0, st, dF, dD, dCoef, dPlane);
+        hipLaunchKernelGGL(jd_color_kernel, dim3((width + 63) / 64, (height + 3) / 4, n), dim3(256), 0, st, dF, dD, dPlane, out_dev, height, width);
+        hipLaunchKernelGGL(jd_status_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dF, dD, dHostRc, dChanged, dStatus, n);
+        JDCHK(hipMemcpyAsync(status, dStatus, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+        JDCHK(hipGetLastError());
+        return 0;
+    }
     for (;;) {
         JDCHK(hipMemsetAsync(dChanged, 0, sizeof(int) * changed.size(), st));
         for (int k = 0; k < JD_PASSES; ++k, ++pass) hipLaunchKernelGGL(jd_sync_kernel, cgrid, dim3(64), 0, st, dF, dD, dClean, dSeg, C, pass, dChanged + (size_t)k * n);

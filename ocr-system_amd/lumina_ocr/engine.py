@@ -68,6 +68,7 @@ def load_library() -> ctypes.CDLL:
         "lumina_ocr_jpeg_encode": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
         "lumina_ocr_jpeg_probe": (i32, [vp, sz, vp]),
         "lumina_ocr_jpeg_last_passes": (i32, [vp]),
+        "lumina_ocr_jpeg_decode_async": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp]),
         "lumina_ocr_jpeg_decode": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
         "lumina_ocr_jpeg_coefficients": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
         "lumina_ocr_load_svtr_weights": (i32, [vp, vp, sz]),
@@ -99,7 +100,7 @@ EXPORTED_SYMBOLS = [
     "lumina_ocr_load_det_weights", "lumina_ocr_load_rec_weights", "lumina_ocr_num_classes", "lumina_ocr_normalize",
     "lumina_ocr_det_forward", "lumina_ocr_det_postprocess", "lumina_ocr_rec_crop", "lumina_ocr_rec_forward",
     "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing", "lumina_ocr_conv_timing_detail",
-    "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients", "lumina_ocr_jpeg_probe", "lumina_ocr_jpeg_decode", "lumina_ocr_jpeg_last_passes",
+    "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients", "lumina_ocr_jpeg_probe", "lumina_ocr_jpeg_decode", "lumina_ocr_jpeg_decode_async", "lumina_ocr_jpeg_last_passes",
     "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward", "lumina_ocr_svtr_num_classes", "lumina_ocr_svtr_dtype", "lumina_ocr_binarize", "lumina_ocr_grayscale", "lumina_ocr_denoise", "lumina_ocr_deskew", "lumina_ocr_deskew_warp",
 ]
 
@@ -187,6 +188,20 @@ class Engine:
         status = (ctypes.c_int * n)()
         self._chk(self.lib.lumina_ocr_jpeg_decode(self._h, ptrs, sizes, n, int(height), int(width), _ptr(out), status, self._stream()))
         return out, list(status)
+
+    def jpeg_decode_async(self, files, height: int, width: int, out=None, passes: int = 12):
+        """jpeg_decode without host synchronisation: -> (pages uint8 [n,H,W,3] device, status int32 [n] PINNED host tensor).  The status is
+        valid once the current stream has run (e.g. after the event of the results that depend on the pages): 0 ok, -1 / -2 / -4 as
+        jpeg_decode, -5 = `passes` synchronisation passes were not enough for that file (decode the batch again with jpeg_decode)."""
+        torch = _torch()
+        n = len(files)
+        if out is None:
+            out = torch.empty((n, height, width, 3), dtype=torch.uint8, device=torch.device("cuda", self.device))
+        status = torch.zeros((n,), dtype=torch.int32).pin_memory()
+        ptrs = (ctypes.c_char_p * n)(*files)
+        sizes = (ctypes.c_size_t * n)(*[len(f) for f in files])
+        self._chk(self.lib.lumina_ocr_jpeg_decode_async(self._h, ptrs, sizes, n, int(height), int(width), _ptr(out), status.data_ptr(), int(passes), self._stream()))
+        return out, status
 
     @property
     def jpeg_last_passes(self) -> int:

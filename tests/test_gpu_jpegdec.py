@@ -83,3 +83,24 @@ def test_unsupported_corrupt_and_wrong_size_files_are_reported_per_page(engine):
     want = pil_decode(good)
     assert np.array_equal(out[0].cpu().numpy(), want) and np.array_equal(out[5].cpu().numpy(), want)
     assert int(out[1].sum()) == 0 and int(out[2].sum()) == 0 and int(out[3].sum()) == 0     # pages that were not decoded are not written
+
+
+def test_async_decode_equals_the_synchronous_one_and_reports_too_few_passes(engine):
+    """lumina_ocr_jpeg_decode_async: no host synchronisation inside the call; the pinned status is valid after the stream has run.
+    Same bytes as the synchronous form; with too few passes a busy file reports -5 instead of wrong pixels going unnoticed."""
+    rng = np.random.default_rng(4)
+    files = []
+    for k in range(3):
+        buf = io.BytesIO()
+        Image.fromarray(rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)).save(buf, format="JPEG", quality=95)
+        files.append(buf.getvalue())
+    files.append(make_file(UNSUPPORTED[0]))
+    ref, st_ref = engine.jpeg_decode(files, 480, 640)
+    out, st = engine.jpeg_decode_async(files, 480, 640, passes=16)
+    out2, st2 = engine.jpeg_decode_async(files, 480, 640, passes=16)          # back to back: the staging buffers alternate
+    torch.cuda.synchronize()
+    assert st_ref == [0, 0, 0, -2] and st.tolist() == [0, 0, 0, -2] and st2.tolist() == [0, 0, 0, -2]
+    assert torch.equal(out[:3], ref[:3]) and torch.equal(out2[:3], ref[:3])
+    few, st_few = engine.jpeg_decode_async(files, 480, 640, passes=2)
+    torch.cuda.synchronize()
+    assert st_few.tolist()[3] == -2 and -5 in st_few.tolist()[:3]             # ~100 KB of noise per file: two passes cannot synchronise ~100 chunks
