@@ -29,7 +29,7 @@ PAGES_PER_RANK = 64
 A4_H, A4_W = 2339, 1654
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (bf16 and fp16 dense alike)
 HBM_PEAK_GBS = 8000.0                  # same guide: HBM3E spec peak
-PMC_FILE = "r02_pmc_hbm.json"          # {"source_sha16": {file: sha}, "kernels": {name: {"hbm_bytes_per_launch": ...}}} (tools/pmc_to_json.py)
+PMC_FILE = "r03_pmc_hbm.json"          # {"source_sha16": {file: sha}, "kernels": {name: {"hbm_bytes_per_launch": ...}}} (tools/pmc_to_json.py)
 
 
 def make_pages(torch, n, seed, device):
