@@ -5,8 +5,9 @@ R = Path(__file__).resolve().parent.parent
 O, P = R / "gpurun_out" / "rec", R / "profiles"
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 def stats(d):
-    f = glob.glob(str(O / d / "**" / "*kernel_stats.csv"), recursive=True)
-    return f[0] if f else None
+    import os
+    f = glob.glob(str(O / d / "**" / "*kernel_stats.csv"), recursive=True)   # (gpurun MERGES into gpurun_out/: older calls' files may still lie there)
+    return max(f, key=os.path.getmtime) if f else None
 copies = {"pmc_hbm.json": "%s_pmc_hbm.json", "bench_line.json": "%s_bench_line.json", "per_layer.txt": "%s_det_per_layer.txt",
           "config2_line.json": "%s_config2_det_only_line.json", "config3_line.json": "%s_config3_rec_only_line.json", "config5_line.json": "%s_config5_svtr_base_f16_line.json"}
 for src, dst in copies.items():
