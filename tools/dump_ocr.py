@@ -13,24 +13,22 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "ocr-system_amd"))
 
 
+# the harness's JSON contract, as a schema: key -> how it is read off the provider's result objects (order = the order of the keys in
+# /root/reference/azure_debug_output.json, the fixture tests/golden/azure_debug_output.json holds)
+SAMPLE_BOXES = 10
+DOC_KEYS = (("success", lambda r: r.success), ("total_pages", lambda r: r.total_pages),
+            ("combined_layout_boxes_count", lambda r: len(r.combined_layout_boxes)),
+            ("combined_layout_boxes_sample", lambda r: list(r.combined_layout_boxes[:SAMPLE_BOXES])))
+PAGE_KEYS = (("page_number", lambda pg: pg.page_number), ("layout_boxes_count", lambda pg: len(pg.layout_boxes)),
+             ("has_processed_image", lambda pg: pg.processed_image_bytes is not None),
+             ("page_width_inches", lambda pg: pg.page_width_inches), ("page_height_inches", lambda pg: pg.page_height_inches))
+
+
 def dump_dict(result) -> dict:
-    """DocumentOCRResult -> the harness's output_data (same keys, same order)."""
-    return {
-        "success": result.success,
-        "total_pages": result.total_pages,
-        "combined_layout_boxes_count": len(result.combined_layout_boxes),
-        "combined_layout_boxes_sample": result.combined_layout_boxes[:10] if result.combined_layout_boxes else [],
-        "pages": [
-            {
-                "page_number": page.page_number,
-                "layout_boxes_count": len(page.layout_boxes),
-                "has_processed_image": page.processed_image_bytes is not None,
-                "page_width_inches": page.page_width_inches,
-                "page_height_inches": page.page_height_inches,
-            }
-            for page in result.pages
-        ],
-    }
+    """DocumentOCRResult -> the harness's output (same keys, same order)."""
+    out = {key: read(result) for key, read in DOC_KEYS}
+    out["pages"] = [{key: read(pg) for key, read in PAGE_KEYS} for pg in result.pages]
+    return out
 
 
 async def main(path: str, out: str) -> int:
