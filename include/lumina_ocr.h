@@ -106,6 +106,9 @@ int lumina_ocr_binarize(lumina_ocr_t* h, const uint8_t* img_dev, int n, int heig
 /* optimize_for_ocr's optional steps (image_preprocessing.py:225-231; both off by default in the reference's callers):
  * convert_to_grayscale (:167-169) = PIL convert('L'), written to all three channels of the page; denoise (:160-165) = PIL
  * MedianFilter(3), per channel, image edge-replicated.  uint8 [n,H,W,3] in and out (denoise: not in place); byte-exact with Pillow. */
+/* auto_orient (image_preprocessing.py:171-173, first step of optimize_for_ocr :213) = PIL ImageOps.exif_transpose: EXIF orientation 1..8
+ * applied on the device (the companion of lumina_ocr_jpeg_decode for camera / phone files); out_dev is [n][width][height][3] for 5..8. */
+int lumina_ocr_exif_transpose(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, int orientation, uint8_t* out_dev, void* stream);
 int lumina_ocr_grayscale(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, uint8_t* out_dev, void* stream);
 int lumina_ocr_denoise(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, uint8_t* out_dev, void* stream);
 

@@ -363,6 +363,14 @@ int lumina_ocr_binarize(lumina_ocr_t* h, const uint8_t* img_dev, int n, int heig
     return e == hipSuccess ? 0 : locr_fail(h, "binarize", hipGetErrorString(e));
 }
 
+int lumina_ocr_exif_transpose(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, int orientation, uint8_t* out_dev, void* stream) {
+    if (!h || !img_dev || !out_dev || n <= 0 || height <= 0 || width <= 0 || orientation < 1 || orientation > 8 || img_dev == out_dev)
+        return locr_fail(h, "exif_transpose", "bad arguments (orientation 1..8, not in place)");
+    BIND(h);
+    hipError_t e = exif_transpose_launch(img_dev, out_dev, n, height, width, orientation, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : locr_fail(h, "exif_transpose", hipGetErrorString(e));
+}
+
 int lumina_ocr_grayscale(lumina_ocr_t* h, const uint8_t* img_dev, int n, int height, int width, uint8_t* out_dev, void* stream) {
     if (!h || !img_dev || !out_dev || n <= 0 || height <= 0 || width <= 0) return locr_fail(h, "grayscale", "bad arguments");
     BIND(h);

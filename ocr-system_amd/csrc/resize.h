@@ -19,3 +19,5 @@ hipError_t binarize_launch(const uint8_t* img, uint8_t* out, int N, int H, int W
 // PIL MedianFilter(3) (edge-replicated); RGB u8 [N,H,W,3] in and out, byte-exact with Pillow (tests/golden/preprocess_vectors.npz)
 hipError_t grayscale_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, hipStream_t st);
 hipError_t median3_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, hipStream_t st);
+// ImageOps.exif_transpose (auto_orient): EXIF orientation 1..8 applied to RGB u8 [N,H,W,3]; out is [N,W,H,3] for orientations 5..8
+hipError_t exif_transpose_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, int orientation, hipStream_t st);

@@ -533,6 +533,36 @@ __global__ __launch_bounds__(256) void median3_kernel(const uint8_t* img, uint8_
 }
 }  // namespace
 
+namespace {
+// ImageOps.exif_transpose (auto_orient, image_preprocessing.py:171-173 / :213): EXIF orientation 2..8 as a pixel permutation.  out (y, x) <- in (sy, sx);
+// orientations 5..8 swap width and height.  One thread per output pixel (3 bytes); the reads of the transposing modes stride through the input.
+__global__ __launch_bounds__(256) void exif_transpose_kernel(const uint8_t* img, uint8_t* out, int H, int W, int orientation) {
+    const int Ho = orientation >= 5 ? W : H, Wo = orientation >= 5 ? H : W;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= Wo || y >= Ho) return;
+    int sy, sx;
+    switch (orientation) {
+        case 2: sy = y; sx = W - 1 - x; break;
+        case 3: sy = H - 1 - y; sx = W - 1 - x; break;
+        case 4: sy = H - 1 - y; sx = x; break;
+        case 5: sy = x; sx = y; break;
+        case 6: sy = H - 1 - x; sx = y; break;
+        case 7: sy = H - 1 - x; sx = W - 1 - y; break;
+        case 8: sy = x; sx = W - 1 - y; break;
+        default: sy = y; sx = x; break;
+    }
+    const uint8_t* s = img + (((size_t)blockIdx.z * H + sy) * W + sx) * 3;
+    uint8_t* d = out + (((size_t)blockIdx.z * Ho + y) * Wo + x) * 3;
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+}  // namespace
+
+hipError_t exif_transpose_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, int orientation, hipStream_t st) {
+    const int Ho = orientation >= 5 ? W : H, Wo = orientation >= 5 ? H : W;
+    hipLaunchKernelGGL(exif_transpose_kernel, dim3((Wo + 63) / 64, (Ho + 3) / 4, N), dim3(256), 0, st, img, out, H, W, orientation);
+    return hipGetLastError();
+}
+
 hipError_t grayscale_launch(const uint8_t* img, uint8_t* out, int N, int H, int W, hipStream_t st) {
     const long long npix = (long long)N * H * W;
     long long g = (npix + 255) / 256;

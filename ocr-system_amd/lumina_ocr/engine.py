@@ -77,6 +77,7 @@ def load_library() -> ctypes.CDLL:
         "lumina_ocr_svtr_dtype": (i32, [vp]),
         "lumina_ocr_binarize": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
         "lumina_ocr_grayscale": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+        "lumina_ocr_exif_transpose": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
         "lumina_ocr_denoise": (i32, [vp, vp, i32, i32, i32, vp, vp]),
         "lumina_ocr_deskew": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "lumina_ocr_deskew_warp": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
@@ -101,7 +102,7 @@ EXPORTED_SYMBOLS = [
     "lumina_ocr_det_forward", "lumina_ocr_det_postprocess", "lumina_ocr_rec_crop", "lumina_ocr_rec_forward",
     "lumina_ocr_ctc_decode", "lumina_ocr_conv2d", "lumina_ocr_read_tap", "lumina_ocr_conv_timing", "lumina_ocr_conv_timing_detail",
     "lumina_ocr_resize_lanczos", "lumina_ocr_enhance", "lumina_ocr_jpeg_encode", "lumina_ocr_jpeg_coefficients", "lumina_ocr_jpeg_probe", "lumina_ocr_jpeg_decode", "lumina_ocr_jpeg_decode_async", "lumina_ocr_jpeg_last_passes",
-    "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward", "lumina_ocr_svtr_num_classes", "lumina_ocr_svtr_dtype", "lumina_ocr_binarize", "lumina_ocr_grayscale", "lumina_ocr_denoise", "lumina_ocr_deskew", "lumina_ocr_deskew_warp",
+    "lumina_ocr_load_svtr_weights", "lumina_ocr_svtr_forward", "lumina_ocr_svtr_num_classes", "lumina_ocr_svtr_dtype", "lumina_ocr_binarize", "lumina_ocr_exif_transpose", "lumina_ocr_grayscale", "lumina_ocr_denoise", "lumina_ocr_deskew", "lumina_ocr_deskew_warp",
 ]
 
 
@@ -411,6 +412,18 @@ class Engine:
         assert c == 3 and img.dtype == torch.uint8
         out = torch.empty_like(img)
         self._chk(self.lib.lumina_ocr_binarize(self._h, _ptr(img), n, h, w, int(bool(adaptive)), int(threshold), _ptr(out), self._stream()))
+        return out
+
+    def exif_transpose(self, img, orientation: int):
+        """auto_orient / ImageOps.exif_transpose (image_preprocessing.py:171-173) for EXIF orientation 1..8.  uint8 [n,H,W,3] device -> [n,H,W,3]
+        (1..4) or [n,W,H,3] (5..8)."""
+        torch = _torch()
+        n, h, w, c = img.shape
+        assert c == 3 and img.dtype == torch.uint8
+        if orientation in (0, 1):
+            return img
+        out = torch.empty((n, w, h, 3) if orientation >= 5 else (n, h, w, 3), dtype=torch.uint8, device=img.device)
+        self._chk(self.lib.lumina_ocr_exif_transpose(self._h, _ptr(img), n, h, w, int(orientation), _ptr(out), self._stream()))
         return out
 
     def grayscale(self, img):

@@ -281,15 +281,16 @@ class OCRService:
                                  image_width=original_size[0], image_height=original_size[1])
 
     def _decode_jpeg_on_device(self, data: bytes, image: Image.Image):
-        """The reference decodes every input with Image.open (image_preprocessing.py:57-75).  For a baseline JPEG without an EXIF rotation
+        """The reference decodes every input with Image.open (image_preprocessing.py:57-75).  For a baseline JPEG
         the pixels are produced on the device instead (lumina_ocr_jpeg_decode: byte-identical to Pillow's decode; grey files arrive with
         their value on all three channels, which is what convert('RGB') gives): nothing is decoded on the host, the file's
         entropy-coded bytes are what crosses PCIe (~10x less than the pixels).  -> device tensor [1,H,W,3], or None: Pillow decodes."""
         if not self.device_jpeg or image.format != "JPEG" or data[:2] != b"\xff\xd8":
             return None
         try:
-            if image.getexif().get(0x0112, 1) not in (0, 1):
-                return None                                   # an orientation to apply: the host path (ImageOps.exif_transpose)
+            orientation = image.getexif().get(0x0112, 1)
+            if orientation not in range(0, 9):
+                return None
             from ..engine import Engine
             rc, info = Engine.jpeg_probe(data)
             if rc != 0 or (info["width"], info["height"]) != image.size:
@@ -297,7 +298,9 @@ class OCRService:
             self._ensure_engine()
             with self._device_ctx():
                 out, status = self._engine.jpeg_decode([data], info["height"], info["width"])
-            return out if status == [0] else None
+                if status != [0]:
+                    return None
+                return self._engine.exif_transpose(out, orientation)     # auto_orient (image_preprocessing.py:213), on the device as well
         except Exception as e:       # any doubt: the reference's own path
             logger.warning("device JPEG decode not used: %s", e)
             return None

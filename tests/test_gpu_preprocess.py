@@ -96,6 +96,25 @@ def test_resize_alignment_cases_vs_oracle(engine, case):
     assert np.array_equal(got2, got)
 
 
+def test_exif_transpose_equals_pillow_for_every_orientation(engine):
+    """auto_orient (image_preprocessing.py:171-173 = ImageOps.exif_transpose) on the device: all eight EXIF orientations, odd sizes, a batch."""
+    import io
+    from PIL import Image, ImageOps
+    rng = np.random.default_rng(8)
+    pages = rng.integers(0, 256, (3, 37, 53, 3), dtype=np.uint8)
+    d = torch.from_numpy(pages).cuda()
+    for o in range(1, 9):
+        got = engine.exif_transpose(d, o).cpu().numpy()
+        for k in range(3):
+            ex = Image.Exif()
+            ex[0x0112] = o
+            buf = io.BytesIO()
+            Image.fromarray(pages[k]).save(buf, format="PNG", exif=ex)
+            buf.seek(0)
+            want = np.asarray(ImageOps.exif_transpose(Image.open(buf)))
+            assert got[k].shape == want.shape and np.array_equal(got[k], want), (o, k)
+
+
 def test_grayscale_and_denoise_are_byte_exact_with_the_reference(engine):
     """convert_to_grayscale / denoise (image_preprocessing.py:160-169) and optimize_for_ocr(apply_denoise=True, grayscale=True) (:191-242)
     on the device vs the reference module's own outputs (tests/golden/preprocess_vectors.npz: gray*, denoise*, optimize_dn*, optimize_dn_gray*)."""

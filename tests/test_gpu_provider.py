@@ -125,17 +125,25 @@ def test_jpeg_inputs_are_decoded_on_the_device_with_the_same_result(service, tmp
     for r in (dev_path, dev_bytes, doc.pages[0]):
         assert r.success and r.layout_boxes == host.layout_boxes and r.markdown == host.markdown
         assert r.processed_image_bytes == host.processed_image_bytes and (r.image_width, r.image_height) == (1000, 700)
-    # files the device decoder does not take: same results through Pillow, no device decode call
-    prog = tmp_path / "prog.jpg"
-    Image.fromarray(page).save(prog, format="JPEG", quality=92, progressive=True)
+    # an EXIF-rotated file: decoded AND re-oriented on the device (lumina_ocr_exif_transpose = ImageOps.exif_transpose): same result as the host path
     rot = tmp_path / "rot.jpg"
     ex = Image.Exif()
     ex[0x0112] = 6
     Image.fromarray(page).save(rot, format="JPEG", quality=92, exif=ex)
+    n0 = len(calls)
+    r_rot = s.process_image_sync(rot)
+    s.device_jpeg = False
+    r_rot_host = s.process_image_sync(rot)
+    s.device_jpeg = True
+    assert len(calls) == n0 + 1 and r_rot.success and r_rot_host.success
+    assert r_rot.layout_boxes == r_rot_host.layout_boxes and r_rot.processed_image_bytes == r_rot_host.processed_image_bytes
+    assert (r_rot.image_width, r_rot.image_height) == (1000, 700)          # original size as stored (ocr_service.py:406), boxes on the rotated page
+    assert r_rot.page_width_inches == 700.0 and r_rot.page_height_inches == 1000.0
+    # files the device decoder does not take: same results through Pillow, no device decode call
+    prog = tmp_path / "prog.jpg"
+    Image.fromarray(page).save(prog, format="JPEG", quality=92, progressive=True)
     png = tmp_path / "page.png"
     Image.fromarray(page).save(png)
     n0 = len(calls)
-    r_prog, r_rot, r_png = s.process_image_sync(prog), s.process_image_sync(rot), s.process_image_sync(png)
-    assert len(calls) == n0 and r_prog.success and r_rot.success and r_png.success
-    assert (r_rot.image_width, r_rot.image_height) == (1000, 700)          # original size as stored (ocr_service.py:406), boxes on the rotated page
-    assert r_rot.page_width_inches == 700.0 and r_rot.page_height_inches == 1000.0
+    r_prog, r_png = s.process_image_sync(prog), s.process_image_sync(png)
+    assert len(calls) == n0 and r_prog.success and r_png.success
